@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (the reference checkout is not present on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--ref /root/reference]
+
+It imports the reference's model and beam search unchanged, feeds them seeded synthetic
+inputs with the value ranges of the reference's configs, and stores inputs, weights and the
+reference's outputs as .npz files.  Nothing of the reference's source is stored, only data.
+Model cases run in eval mode with autograd on (dropout off; BatchNorm still uses batch
+statistics because track_running_stats=False, src/gcn/models/gcn_layers.py:10,30).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def make_graph_batch(rng, B, V, C, cap_lo, cap_hi, dem_lo, dem_hi, extra_edges=0.15):
+    """Symmetric capacitated graphs (ring + random chords, equal capacity both ways, zero
+    diagonal, 0 = no edge) and commodities (distinct src != dst, sorted by demand descending,
+    src/common/graph/graph_utils.py:269-281)."""
+    cap = np.zeros((B, V, V), dtype=np.float32)
+    comm = np.zeros((B, C, 3), dtype=np.int64)
+    for b in range(B):
+        for i in range(V):
+            j = (i + 1) % V
+            c = rng.integers(cap_lo, cap_hi)
+            cap[b, i, j] = cap[b, j, i] = c
+        for i in range(V):
+            for j in range(i + 2, V):
+                if rng.random() < extra_edges and cap[b, i, j] == 0:
+                    c = rng.integers(cap_lo, cap_hi)
+                    cap[b, i, j] = cap[b, j, i] = c
+        pairs = set()
+        rows = []
+        while len(rows) < C:
+            s, t = rng.integers(0, V, size=2)
+            if s == t or (s, t) in pairs:
+                continue
+            pairs.add((s, t))
+            rows.append([s, t, rng.integers(dem_lo, dem_hi + 1)])
+        rows.sort(key=lambda r: -r[2])
+        comm[b] = np.asarray(rows)
+    return cap, comm
+
+
+def nodes_from_commodities(comm, V):
+    """x_nodes[b, src, c] = 1, x_nodes[b, dst, c] = 2 (src/common/data_management/dataset_reader.py:119-123)."""
+    B, C, _ = comm.shape
+    x_nodes = np.zeros((B, V, C), dtype=np.int64)
+    for b in range(B):
+        for c in range(C):
+            x_nodes[b, comm[b, c, 0], c] = 1
+            x_nodes[b, comm[b, c, 1], c] = 2
+    return x_nodes
+
+
+# ----------------------------------------------------------------------------- model cases
+def run_model_case(name, B, V, C, H, L, mlp_layers=2, aggregation="mean", voc=2, mask=False,
+                   seed=0, keep_layers=True, cap_rng=(1000, 10000), dem_rng=(1, 500)):
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    from src.gcn.models.model_utils import edge_error
+    from src.common.config.config import Settings
+
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    cfg = dict(num_nodes=V, num_commodities=C, voc_edges_in=3, voc_edges_out=voc, hidden_dim=H,
+               num_layers=L, mlp_layers=mlp_layers, aggregation=aggregation)
+    model = ResidualGatedGCNModel(Settings(cfg), torch.float32, torch.long)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "batch_norm.weight" in n:
+                p.add_(0.2 * torch.randn_like(p))
+            if "batch_norm.bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    model.eval()
+    cap, comm = make_graph_batch(rng, B, V, C, cap_rng[0], cap_rng[1], dem_rng[0], dem_rng[1])
+    x_nodes = nodes_from_commodities(comm, V)
+    y_edges = (rng.random((B, V, V, C)) < 0.12).astype(np.int64)
+    n1 = y_edges.sum()
+    n = y_edges.size
+    edge_cw = np.asarray([n / (2.0 * (n - n1)), n / (2.0 * n1)], dtype=np.float32)  # sklearn "balanced"
+    x_edges = (cap > 0).astype(np.int64)
+
+    t = lambda a: torch.from_numpy(a)
+    out = {"cfg_B": B, "cfg_V": V, "cfg_C": C, "cfg_H": H, "cfg_L": L, "cfg_mlp_layers": mlp_layers,
+           "cfg_aggregation": aggregation, "cfg_voc": voc, "cfg_mask": int(mask),
+           "in_cap": cap, "in_comm": comm, "in_x_nodes": x_nodes, "in_y_edges": y_edges, "in_edge_cw": edge_cw}
+    for k, v in model.state_dict().items():
+        out["param." + k] = v.detach().numpy().copy()
+
+    # hooks to capture per-layer outputs of the reference
+    layer_out = []
+    hooks = [lyr.register_forward_hook(lambda m, i, o: layer_out.append(o)) for lyr in model.gcn_layers]
+    demand = t(comm[:, :, 2].astype(np.float32))
+    if voc == 2:
+        y_pred, loss = model(t(x_edges), demand, t(cap), t(x_nodes), t(y_edges), edge_cw)
+        loss.backward()
+        err, err_idx = edge_error(y_pred, t(y_edges), t(x_edges))
+        out["out_loss"] = np.float32(loss.item())
+        out["out_edge_error"] = np.float64(err)
+        out["out_err_idx"] = err_idx.numpy()
+    else:
+        # score head (voc_edges_out=1): no loss inside the model; backprop a fixed linear functional
+        y_pred, loss = model(t(x_edges), demand, t(cap), t(x_nodes), compute_loss=False, mask_invalid_edges=mask)
+        assert loss is None
+        R = rng.standard_normal(tuple(y_pred.shape)).astype(np.float32)
+        out["in_dy_pred"] = R
+        (y_pred * t(R)).sum().backward()
+    for h in hooks:
+        h.remove()
+    out["out_y_pred"] = y_pred.detach().numpy()
+    for k, p in model.named_parameters():
+        out["grad." + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    out["out_x_last"] = layer_out[-1][0].detach().numpy()
+    if keep_layers:
+        for l, (x_l, e_l) in enumerate(layer_out):
+            out[f"layer{l}.x"] = x_l.detach().numpy()
+            out[f"layer{l}.e"] = e_l.detach().numpy()
+    else:
+        out["out_e_last_slice"] = layer_out[-1][1].detach().numpy()[0, :3]  # [3,V,C,H] slice of graph 0
+    path = os.path.join(OUT, f"model_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={out.get('out_loss')} -> {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+# ----------------------------------------------------------------------------- beam-search cases
+def run_beam_case(name, B, V, C, K, algorithm, strict, seed, cap_rng=(1000, 5000), dem_rng=(5, 500),
+                  quantize=None, voc=2, max_iter=5, extra_edges=0.2):
+    from src.gcn.algorithms.beamsearch_uelb import BeamSearchFactory
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cap, comm = make_graph_batch(rng, B, V, C, cap_rng[0], cap_rng[1], dem_rng[0], dem_rng[1], extra_edges)
+    if voc == 2:
+        logits = rng.standard_normal((B, V, V, C, 2)).astype(np.float32) * 2.0
+    else:
+        logits = rng.standard_normal((B, V, V, C)).astype(np.float32) * 2.0
+    if quantize:
+        logits = np.round(logits * quantize) / quantize          # few distinct values -> tied scores
+    algo = BeamSearchFactory.create_algorithm(
+        algorithm, y_pred_edges=torch.from_numpy(logits.copy()), beam_size=K, batch_size=B,
+        edges_capacity=torch.from_numpy(cap), commodities=torch.from_numpy(comm),
+        dtypeFloat=torch.float32, dtypeLong=torch.long, mode_strict=strict, max_iter=max_iter)
+    y = algo.y.numpy().copy()
+    if quantize:
+        # force exact ties in the scores themselves as well
+        y = (np.round(y * 4.0) / 4.0).astype(np.float32)
+        y[y == 0] = np.float32(-1e-20)
+        algo.y = torch.from_numpy(y.copy())
+    drawn = []
+    orig_randperm = torch.randperm
+
+    def recording_randperm(n, *a, **kw):
+        p = orig_randperm(n, *a, **kw)
+        drawn.append(p.numpy().astype(np.int32).copy())
+        return p
+
+    torch.randperm = recording_randperm
+    try:
+        paths, feas = [], []
+        for b in range(B):
+            _, p, f = algo._search_single_batch(b)
+            paths.append(p)
+            feas.append(bool(f))
+    finally:
+        torch.randperm = orig_randperm
+    PL = max(V, 10)
+    parr = -np.ones((B, C, PL), dtype=np.int32)
+    plen = np.zeros((B, C), dtype=np.int32)
+    for b in range(B):
+        for c in range(C):
+            p = [int(v) for v in paths[b][c]]
+            parr[b, c, :len(p)] = p
+            plen[b, c] = len(p)
+    perms = np.stack(drawn) if drawn else np.zeros((0, C), dtype=np.int32)
+    out = dict(cfg_B=B, cfg_V=V, cfg_C=C, cfg_K=K, cfg_algorithm=algorithm, cfg_strict=int(strict),
+               cfg_max_iter=max_iter, in_logits=logits, in_y=y, in_cap=cap, in_comm=comm, in_perms=perms,
+               out_paths=parr, out_path_len=plen, out_feasible=np.asarray(feas, dtype=np.int32))
+    path = os.path.join(OUT, f"beam_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: feasible={feas} perms={len(drawn)} -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, args.ref)
+    os.chdir(args.ref)
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+
+    run_model_case("tiny", 2, 5, 3, 8, 2, seed=1)
+    run_model_case("h12_mlp3", 2, 6, 4, 12, 2, mlp_layers=3, seed=2)
+    run_model_case("sum_agg", 2, 5, 3, 8, 2, aggregation="sum", seed=3)
+    run_model_case("voc1_mask", 2, 5, 3, 8, 2, voc=1, mask=True, seed=4)
+    run_model_case("nsf", 3, 14, 10, 64, 2, seed=5, keep_layers=False, cap_rng=(1000, 5000), dem_rng=(5, 500))
+    run_model_case("wide", 2, 40, 5, 64, 1, seed=6, keep_layers=False)
+    run_model_case("h32_l3", 2, 7, 2, 32, 3, seed=7)
+
+    run_beam_case("det_strict", 4, 14, 10, 10, "deterministic", True, seed=11)
+    run_beam_case("det_loose", 3, 10, 5, 3, "deterministic", False, seed=12)
+    run_beam_case("std_strict", 4, 14, 10, 5, "standard", True, seed=13)
+    run_beam_case("std_tight", 4, 8, 6, 3, "standard", True, seed=14, cap_rng=(300, 700), dem_rng=(100, 500))
+    run_beam_case("greedy", 4, 12, 6, 10, "greedy", True, seed=15)
+    run_beam_case("greedy_tight", 3, 8, 6, 4, "greedy", True, seed=16, cap_rng=(300, 700), dem_rng=(100, 500))
+    run_beam_case("unconstrained", 3, 14, 10, 10, "unconstrained", False, seed=17)
+    run_beam_case("ties", 4, 9, 5, 4, "deterministic", True, seed=18, quantize=2)
+    run_beam_case("ties_std", 3, 9, 5, 2, "standard", True, seed=19, quantize=2)
+    run_beam_case("scores4d", 3, 10, 4, 5, "deterministic", True, seed=20, voc=1)
+    run_beam_case("det_tight", 3, 8, 6, 3, "deterministic", True, seed=21, cap_rng=(300, 700), dem_rng=(100, 500))
+    run_beam_case("v40", 2, 40, 5, 10, "deterministic", True, seed=22, extra_edges=0.05)
+
+
+if __name__ == "__main__":
+    main()
