@@ -1,0 +1,184 @@
+// Shared device helpers for the gfx950 GCN kernels.
+//
+// Register layout used by every row-tile kernel ("tile layout"):
+//   a wavefront (64 lanes) owns a tile of 16 rows x HP columns, HP = 16*MT >= H.
+//   lane l = (rs, q) with rs = l & 15 (row slot) and q = l >> 4 (column quarter);
+//   Tile<MT>.v[m] holds columns 16*m + 4*q .. 16*m + 4*q + 3 of row rs.
+// With this layout the lane's own registers are at the same time
+//   * the B operand of v_mfma_f32_16x16x4_f32 (B[k = q][j = rs]) for reduction index
+//     k = 16*s + 4*q + t at step (s, t), and
+//   * the C/D fragment (D[i = 4*q + r][j = rs]) of output block m,
+// so Y = X * W^T maps tile -> tile with no LDS traffic and no cross-lane movement, and every
+// elementwise epilogue (bias, gate, BatchNorm, residual) is lane-local.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GCN_WAVE 64
+#define GCN_BLOCK 256           // 4 wavefronts per workgroup
+#define GCN_WAVES_PER_BLOCK 4
+#define GCN_BN_EPS 1e-5f
+
+template <int MT>
+struct Tile {
+    f32x4 v[MT];
+};
+
+// Weight fragments (A operand): w[m][s] covers output block m, reduction block s;
+// component t multiplies reduction index 16*s + 4*q + t.
+template <int MT>
+struct WFrag {
+    f32x4 w[MT][MT];
+};
+
+__device__ __forceinline__ f32x4 f4zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+template <int MT>
+__device__ __forceinline__ void tile_zero(Tile<MT>& t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) t.v[m] = f4zero();
+}
+
+// row == nullptr (row slot outside the problem) or column >= H loads zeros.
+template <int MT>
+__device__ __forceinline__ Tile<MT> tile_load(const float* __restrict__ row, int H, int q) {
+    Tile<MT> t;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int col = 16 * m + 4 * q;
+        t.v[m] = (row != nullptr && col < H) ? *reinterpret_cast<const f32x4*>(row + col) : f4zero();
+    }
+    return t;
+}
+
+template <int MT>
+__device__ __forceinline__ void tile_store(float* __restrict__ row, int H, int q, const Tile<MT>& t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int col = 16 * m + 4 * q;
+        if (row != nullptr && col < H) *reinterpret_cast<f32x4*>(row + col) = t.v[m];
+    }
+}
+
+// Fragments of W ([H out][H in], row-major, as torch.nn.Linear stores it) for Y = X * W^T.
+template <int MT>
+__device__ __forceinline__ void wfrag_load_nt(WFrag<MT>& f, const float* __restrict__ W, int H, int rs, int q) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < MT; ++s) {
+            const int n = 16 * m + rs, k = 16 * s + 4 * q;
+            f.w[m][s] = (n < H && k < H) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * H + k) : f4zero();
+        }
+}
+
+// Fragments of W^T for Y = X * W (backward through the same Linear): element [k][n] := W[n][k].
+template <int MT>
+__device__ __forceinline__ void wfrag_load_tr(WFrag<MT>& f, const float* __restrict__ W, int H, int rs, int q) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < MT; ++s) {
+            const int kout = 16 * m + rs;
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 16 * s + 4 * q + t;
+                v[t] = (kout < H && n < H) ? W[(size_t)n * H + kout] : 0.f;
+            }
+            f.w[m][s] = v;
+        }
+}
+
+// out[row][16m + 4q + r] = sum_k in[row][k] * Wf[16m + ..][k]   (exact f32 FMA chain per output)
+template <int MT>
+__device__ __forceinline__ Tile<MT> tile_gemm(const Tile<MT>& in, const WFrag<MT>& f) {
+    Tile<MT> out;
+    tile_zero(out);
+#pragma unroll
+    for (int s = 0; s < MT; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                out.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[m][s][t], in.v[s][t], out.v[m], 0, 0, 0);
+    return out;
+}
+
+// Sum over the 16 row slots; every lane of the 16-lane group ends up with the total.
+__device__ __forceinline__ float red16(float x) {
+    x += __shfl_xor(x, 1, GCN_WAVE);
+    x += __shfl_xor(x, 2, GCN_WAVE);
+    x += __shfl_xor(x, 4, GCN_WAVE);
+    x += __shfl_xor(x, 8, GCN_WAVE);
+    return x;
+}
+template <int MT>
+__device__ __forceinline__ void tile_red16(Tile<MT>& t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.v[m][r] = red16(t.v[m][r]);
+}
+// Sum over the 4 column quarters (lanes with equal rs).
+__device__ __forceinline__ float redq(float x) {
+    x += __shfl_xor(x, 16, GCN_WAVE);
+    x += __shfl_xor(x, 32, GCN_WAVE);
+    return x;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------- counter-based dropout
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// One key per (seed, step, stream id); rng points at two 64-bit words {seed, step} in device memory
+// so that a captured HIP graph sees a new step on every replay.
+struct DropCfg {
+    uint32_t key;
+    uint32_t thresh;   // keep iff (hash >> 8) >= thresh, thresh = p * 2^24
+    float scale;       // 1 / (1 - p)
+    int on;
+};
+__device__ __forceinline__ DropCfg drop_cfg(const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    DropCfg d;
+    d.on = (training && p > 0.f) ? 1 : 0;
+    d.key = 0; d.thresh = 0; d.scale = 1.f;
+    if (d.on) {
+        const unsigned long long seed = rng[0], step = rng[1];
+        uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9U);
+        k = mix32(k ^ (uint32_t)(seed >> 32));
+        k = mix32(k ^ (uint32_t)step);
+        k = mix32(k ^ (uint32_t)(step >> 32) ^ ((uint32_t)stream_id * 0x85EBCA6BU));
+        d.key = k;
+        d.thresh = (p >= 1.f) ? 0x1000000U : (uint32_t)(p * 16777216.0f);
+        d.scale = (p >= 1.f) ? 0.f : 1.0f / (1.0f - p);
+    }
+    return d;
+}
+__device__ __forceinline__ uint32_t drop_rowhash(const DropCfg& d, uint32_t row) { return mix32(row ^ d.key); }
+// multiplier applied to element (row, col): 0 if dropped, 1/(1-p) if kept
+__device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t rowhash, int col) {
+    const uint32_t h = mix32(rowhash + (uint32_t)col * 0x9E3779B9U);
+    return ((h >> 8) >= d.thresh) ? d.scale : 0.f;
+}
+
+// Per-channel BatchNorm constants for the lane's columns.
+template <int MT>
+struct ChanVec {
+    f32x4 v[MT];
+};
+template <int MT>
+__device__ __forceinline__ ChanVec<MT> chan_load(const float* __restrict__ p, int H, int q) {
+    ChanVec<MT> c;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int col = 16 * m + 4 * q;
+        c.v[m] = (p != nullptr && col < H) ? *reinterpret_cast<const f32x4*>(p + col) : f4zero();
+    }
+    return c;
+}

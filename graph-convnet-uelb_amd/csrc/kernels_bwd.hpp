@@ -1,0 +1,566 @@
+// Backward kernels of the residual gated graph-conv stack (gfx950).
+// The reference has no hand-written backward: these kernels restate what autograd derives from
+// src/gcn/models/gcn_layers.py:117-129 and src/gcn/models/model_utils.py:51-78.
+#pragma once
+#include "common.hpp"
+#include "kernels_fwd.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward, reduction pass.  For out = dropout(relu(BN(tmp)) + resid):
+//   dpre = dnew * dropmask ; dbn = dpre * [BN(tmp) > 0] ; xhat = (tmp - mean) * rstd
+// accumulates per channel sum(dbn) and sum(dbn * xhat) into partial[nwaves][2][H].
+// Used for the edge tensor (R_e rows) and the node tensor (R_n rows).
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_stats(
+    size_t rows, int H, const float* __restrict__ dnew, const float* __restrict__ tmp,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ partial,
+    const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
+    const ChanVec<MT> mu = chan_load<MT>(mean, H, q), rsd = chan_load<MT>(rstd, H, q);
+    const ChanVec<MT> ga = chan_load<MT>(gamma, H, q), be = chan_load<MT>(beta, H, q);
+    Tile<MT> a1, a2;
+    tile_zero(a1); tile_zero(a2);
+    const size_t ntiles = (rows + 15) / 16;
+    for (size_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t row = tile * 16 + rs;
+        const bool valid = row < rows;
+        const Tile<MT> dn = tile_load<MT>(valid ? dnew + row * H : nullptr, H, q);
+        const Tile<MT> tp = tile_load<MT>(valid ? tmp + row * H : nullptr, H, q);
+        const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xh = (tp.v[m][r] - mu.v[m][r]) * rsd.v[m][r];
+                const float bn = xh * ga.v[m][r] + be.v[m][r];
+                float d = dn.v[m][r];
+                if (dc.on) d *= drop_mul(dc, rh, 16 * m + 4 * q + r);
+                d = (bn > 0.f && valid) ? d : 0.f;
+                a1.v[m][r] += d;
+                a2.v[m][r] += d * xh;
+            }
+    }
+    tile_red16(a1);
+    tile_red16(a2);
+    if (rs == 0) {
+        float* pp = partial + (size_t)wave * 2 * H;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int col = 16 * m + 4 * q;
+            if (col < H) {
+                *reinterpret_cast<f32x4*>(pp + col) = a1.v[m];
+                *reinterpret_cast<f32x4*>(pp + H + col) = a2.v[m];
+            }
+        }
+    }
+}
+
+// partial [nP][2][H] -> bstats [2][H] = mean(dbn), mean(dbn*xhat); dgamma = sum(dbn*xhat), dbeta = sum(dbn).
+// grid = H/4.
+__global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_finalize(const float* __restrict__ partial, int nP, int H, double n,
+                                                              float* __restrict__ bstats, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ double lds[GCN_BLOCK * 4];
+    const int col = blockIdx.x * 4;
+    double s1[4], s2[4];
+    block_colsum4(partial, nP, 2 * H, col, s1, lds);
+    block_colsum4(partial, nP, 2 * H, H + col, s2, lds);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) {
+            bstats[col + k] = (float)(s1[k] / n);
+            bstats[H + col + k] = (float)(s2[k] / n);
+            dbeta[col + k] = (float)s1[k];
+            dgamma[col + k] = (float)s2[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node side, elementwise: dx_tmp = gamma*rstd*(dbn - m1 - xhat*m2) and qv = dx_tmp / D ("mean") or
+// dx_tmp ("sum"); also dpre = dx_new * dropmask (the residual branch), written to dpre_out.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_node_bwd_pre(size_t rows, int H, const float* __restrict__ dnew, const float* __restrict__ tmp,
+                               const float* __restrict__ Dn, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ bstats,
+                               float* __restrict__ dpre_out, float* __restrict__ dxtmp, float* __restrict__ qv,
+                               const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
+    const int h4 = H / 4;
+    const size_t n4 = rows * (size_t)h4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / h4;
+        const int col = (int)(i - row * h4) * 4;
+        const f32x4 dn = *reinterpret_cast<const f32x4*>(dnew + row * H + col);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tmp + row * H + col);
+        const f32x4 D = *reinterpret_cast<const f32x4*>(Dn + row * H + col);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(bstats + col);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(bstats + H + col);
+        const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
+        f32x4 dpre, dxt, qq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (t[k] - mu[k]) * rs[k];
+            const float bn = xh * ga[k] + be[k];
+            float d = dn[k];
+            if (dc.on) d *= drop_mul(dc, rh, col + k);
+            dpre[k] = d;
+            const float dbn = bn > 0.f ? d : 0.f;
+            const float dx = ga[k] * rs[k] * (dbn - m1[k] - xh * m2[k]);
+            dxt[k] = dx;
+            qq[k] = dx / D[k];
+        }
+        *reinterpret_cast<f32x4*>(dpre_out + row * H + col) = dpre;
+        *reinterpret_cast<f32x4*>(dxtmp + row * H + col) = dxt;
+        *reinterpret_cast<f32x4*>(qv + row * H + col) = qq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge backward, main pass.  One wavefront per (b, c, i-chunk, j-tile): for each i of the chunk it
+// recomputes, for the 16 rows (b, i, j, c):
+//   dpre = de_new * dropmask ; dbn = dpre * [BN > 0] ; g = sigmoid(e_tmp)
+//   det  = gamma*rstd*(dbn - m1 - xhat*m2) + qv[b,i,c] * (Vn[b,j,c] - A[b,i,c]) * g * (1 - g)
+//   de_in = dpre + det * W_U                                   (in place over de)
+// and writes det (consumed by the weight-gradient GEMM), the row sums over j
+// (rowpart[jt][b,i,c,:]) and, accumulated in registers over the chunk's i, the column sums
+//   colVe[it][b,j,c,:] = sum_i det   and   colVn[it][b,j,c,:] = sum_i qv[b,i,c] * g .
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_edge_bwd_main(
+    int B, int V, int C, int H, int IT, int mean_agg,
+    float* __restrict__ de, const float* __restrict__ e_tmp, const float* __restrict__ WU,
+    const float* __restrict__ Vn, const float* __restrict__ Aagg, const float* __restrict__ qv,
+    const float* __restrict__ stats /* mean_e, rstd_e */, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ bstats /* m1, m2 */,
+    float* __restrict__ det_out, float* __restrict__ rowpart, float* __restrict__ colVe, float* __restrict__ colVn,
+    const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
+    const int njt = (V + 15) / 16;
+    const int nit = (V + IT - 1) / IT;
+    const int units = B * nit * njt * C;
+    const size_t Rn = (size_t)B * V * C;
+    WFrag<MT> wf;
+    wfrag_load_tr(wf, WU, H, rs, q);
+    const ChanVec<MT> mu = chan_load<MT>(stats, H, q), rsd = chan_load<MT>(stats + H, H, q);
+    const ChanVec<MT> ga = chan_load<MT>(gamma, H, q), be = chan_load<MT>(beta, H, q);
+    const ChanVec<MT> m1 = chan_load<MT>(bstats, H, q), m2 = chan_load<MT>(bstats + H, H, q);
+    for (int u = wave; u < units; u += nwaves) {
+        // unit order: c fastest so that neighbouring wavefronts touch neighbouring rows
+        int t = u;
+        const int c = t % C; t /= C;
+        const int jt = t % njt; t /= njt;
+        const int it = t % nit;
+        const int b = t / nit;
+        const int j = jt * 16 + rs;
+        const bool valid = j < V;
+        const size_t nrow_j = (size_t)(b * V + j) * C + c;
+        const Tile<MT> vnj = tile_load<MT>(valid ? Vn + nrow_j * H : nullptr, H, q);
+        Tile<MT> cve, cvn;
+        tile_zero(cve); tile_zero(cvn);
+        const int i_end = min(V, (it + 1) * IT);
+        for (int i = it * IT; i < i_end; ++i) {
+            const size_t nrow_i = (size_t)(b * V + i) * C + c;
+            const ChanVec<MT> qi = chan_load<MT>(qv + nrow_i * H, H, q);
+            // "sum" aggregation has no normaliser, so d x_tmp / d gate = Vn[b,j,c] alone
+            const ChanVec<MT> ai = chan_load<MT>(mean_agg ? Aagg + nrow_i * H : nullptr, H, q);
+            const size_t erow = ((size_t)(b * V + i) * V + j) * C + c;
+            const Tile<MT> dn = tile_load<MT>(valid ? de + erow * H : nullptr, H, q);
+            const Tile<MT> tp = tile_load<MT>(valid ? e_tmp + erow * H : nullptr, H, q);
+            const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
+            Tile<MT> det, dpre;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = tp.v[m][r];
+                    const float xh = (x - mu.v[m][r]) * rsd.v[m][r];
+                    const float bn = xh * ga.v[m][r] + be.v[m][r];
+                    float d = dn.v[m][r];
+                    if (dc.on) d *= drop_mul(dc, rh, 16 * m + 4 * q + r);
+                    dpre.v[m][r] = d;
+                    const float dbn = bn > 0.f ? d : 0.f;
+                    const float g = sigmoidf_(x);
+                    float v = ga.v[m][r] * rsd.v[m][r] * (dbn - m1.v[m][r] - xh * m2.v[m][r]);
+                    v += qi.v[m][r] * (vnj.v[m][r] - ai.v[m][r]) * g * (1.f - g);
+                    v = valid ? v : 0.f;
+                    det.v[m][r] = v;
+                    cve.v[m][r] += v;
+                    cvn.v[m][r] += valid ? qi.v[m][r] * g : 0.f;
+                }
+            tile_store(valid ? det_out + erow * H : nullptr, H, q, det);
+            Tile<MT> din = tile_gemm(det, wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) din.v[m] += dpre.v[m];
+            tile_store(valid ? de + erow * H : nullptr, H, q, din);
+            tile_red16(det);   // row sums over the tile's j
+            if (rs == 0) {
+                float* rp = rowpart + ((size_t)jt * Rn + nrow_i) * H;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int col = 16 * m + 4 * q;
+                    if (col < H) *reinterpret_cast<f32x4*>(rp + col) = det.v[m];
+                }
+            }
+        }
+        tile_store(valid ? colVe + ((size_t)it * Rn + nrow_j) * H : nullptr, H, q, cve);
+        tile_store(valid ? colVn + ((size_t)it * Rn + nrow_j) * H : nullptr, H, q, cvn);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node backward: gathers the partial sums, forms
+//   dVe[b,v,c] = sum_jt rowpart + sum_it colVe,  dVn[b,v,c] = sum_it colVn,  dUx = dx_tmp
+// and dx_in = dpre + dUx W_nU + dVn W_nV + dVe W_eV (in place over dx, which holds dpre on entry).
+// dVe/dVn are written out for the weight-gradient GEMMs.  One wavefront per 16-row tile.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_node_bwd(
+    int rows, int H, int njt, int nit, const float* __restrict__ rowpart, const float* __restrict__ colVe,
+    const float* __restrict__ colVn, const float* __restrict__ dxtmp, const float* __restrict__ WnU,
+    const float* __restrict__ WnV, const float* __restrict__ WeV, float* __restrict__ dx,
+    float* __restrict__ dVe_out, float* __restrict__ dVn_out) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const int ntiles = (rows + 15) / 16;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int row = tile * 16 + rs;
+        const bool valid = row < rows;
+        Tile<MT> dve, dvn;
+        tile_zero(dve); tile_zero(dvn);
+        for (int k = 0; k < njt; ++k) {
+            const Tile<MT> t = tile_load<MT>(valid ? rowpart + ((size_t)k * rows + row) * H : nullptr, H, q);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dve.v[m] += t.v[m];
+        }
+        for (int k = 0; k < nit; ++k) {
+            const Tile<MT> t = tile_load<MT>(valid ? colVe + ((size_t)k * rows + row) * H : nullptr, H, q);
+            const Tile<MT> t2 = tile_load<MT>(valid ? colVn + ((size_t)k * rows + row) * H : nullptr, H, q);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { dve.v[m] += t.v[m]; dvn.v[m] += t2.v[m]; }
+        }
+        tile_store(valid ? dVe_out + (size_t)row * H : nullptr, H, q, dve);
+        tile_store(valid ? dVn_out + (size_t)row * H : nullptr, H, q, dvn);
+        Tile<MT> acc = tile_load<MT>(valid ? dx + (size_t)row * H : nullptr, H, q);
+        const Tile<MT> dux = tile_load<MT>(valid ? dxtmp + (size_t)row * H : nullptr, H, q);
+        {
+            WFrag<MT> wf;
+            wfrag_load_tr(wf, WnU, H, rs, q);
+            const Tile<MT> o = tile_gemm(dux, wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
+        }
+        {
+            WFrag<MT> wf;
+            wfrag_load_tr(wf, WnV, H, rs, q);
+            const Tile<MT> o = tile_gemm(dvn, wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
+        }
+        {
+            WFrag<MT> wf;
+            wfrag_load_tr(wf, WeV, H, rs, q);
+            const Tile<MT> o = tile_gemm(dve, wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
+        }
+        tile_store(valid ? dx + (size_t)row * H : nullptr, H, q, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM with the reduction over rows: dW[n][k] = sum_row X[row][n] * Y[row][k] and
+// db[n] = sum_row X[row][n], split over gridDim.x row slices.  Up to 3 (X, Y) problems per launch
+// (blockIdx.z).  Each wavefront owns one 16-wide block of n (block m = blockIdx.y*4 + wave) and all
+// k; operands are read straight from global memory in MFMA order (A[i = n][kk = row], B[kk = row][j = k]).
+// partial layout: [slice][prob][H*H + H].
+// ------------------------------------------------------------------------------------------------
+struct TnProblems {
+    const float* X[3];
+    const float* Y[3];
+};
+
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_gemm_tn(size_t rows, int H, int nprob, TnProblems pr,
+                                                      float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int m = blockIdx.y * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int prob = blockIdx.z;
+    const int slice = blockIdx.x, nslices = gridDim.x;
+    const float* __restrict__ X = pr.X[prob];
+    const float* __restrict__ Y = pr.Y[prob];
+    const size_t ntiles = (rows + 15) / 16;
+    const size_t per = (ntiles + nslices - 1) / nslices;
+    const size_t t0 = (size_t)slice * per, t1 = min(ntiles, t0 + per);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) acc[k] = f4zero();
+    float bsum = 0.f;
+    const int n = 16 * m + rs;
+    if (m < MT) {
+        for (size_t tile = t0; tile < t1; ++tile) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const size_t row = tile * 16 + st * 4 + q;
+                const bool valid = row < rows;
+                const float a = (valid && n < H) ? X[row * H + n] : 0.f;
+                bsum += a;
+#pragma unroll
+                for (int k = 0; k < MT; ++k) {
+                    const int kc = 16 * k + rs;
+                    const float bval = (valid && kc < H) ? Y[row * H + kc] : 0.f;
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[k], 0, 0, 0);
+                }
+            }
+        }
+        // D[i = n-slot 4q + r][j = k-slot rs]
+        float* out = partial + ((size_t)slice * nprob + prob) * ((size_t)H * H + H);
+#pragma unroll
+        for (int k = 0; k < MT; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = 16 * m + 4 * q + r, kc = 16 * k + rs;
+                if (nn < H && kc < H) out[(size_t)nn * H + kc] = acc[k][r];
+            }
+        bsum = redq(bsum);
+        if (q == 0 && n < H) out[(size_t)H * H + n] = bsum;
+    }
+}
+
+// Sum of nP partial slabs of ncols floats -> up to 8 destination tensors: column range
+// [off[d], off[d+1]) of the slab goes to dst[d].  Fixed order, fp32 pairwise-free serial sum in fp64.
+struct ReduceDst {
+    float* dst[8];
+    int off[9];
+    int n;
+};
+__global__ void k_reduce_slabs(const float* __restrict__ partial, int nP, int ncols, ReduceDst rd) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    double s = 0;
+    for (int p = 0; p < nP; ++p) s += partial[(size_t)p * ncols + col];
+    for (int d = 0; d < rd.n; ++d)
+        if (col >= rd.off[d] && col < rd.off[d + 1]) { rd.dst[d][col - rd.off[d]] = (float)s; break; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head backward.  Recomputes the hidden activations of the edge MLP, forms
+//   dlogit[v] = gl * w[y] * (softmax_v - [v == y]) / sum_w  (+ dy_pred[row][v])      (loss_edges backward)
+// with zero gradient on masked (-1e9) edges, walks back through the NHID hidden layers, writes
+// de = d loss / d e_L, the pre-activation gradients dpre_k (for the weight-gradient GEMM) and, for
+// k >= 1, the layer inputs h_{k-1}; accumulates d outW / d outB per wavefront.
+// wpartial layout: [nwaves][wstride], wstride = voc*H + voc rounded up to a multiple of 4 floats.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NHID>
+__global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ e,
+    const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
+    const float* __restrict__ edge_cw, const float* __restrict__ loss_out /* [1] = sum w */,
+    const float* __restrict__ dloss, const float* __restrict__ dy_pred,
+    float* __restrict__ de, float* __restrict__ dpre_stash /* [NHID][rows*H] */,
+    float* __restrict__ h_stash /* [NHID-1][rows*H] */, float* __restrict__ wpartial,
+    const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const size_t ntiles = (rows + 15) / 16;
+    ChanVec<MT> w2[2];
+    w2[0] = chan_load<MT>(hp.outW, H, q);
+    w2[1] = chan_load<MT>(voc > 1 ? hp.outW + H : nullptr, H, q);
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    const bool has_loss = (y_edges != nullptr) && voc == 2;
+    const float gl = has_loss ? (dloss ? dloss[0] : 1.f) / loss_out[1] : 0.f;
+    Tile<MT> dw2a, dw2b;          // per-lane partial d outW rows 0 / 1
+    tile_zero(dw2a); tile_zero(dw2b);
+    float db2a = 0.f, db2b = 0.f;
+    for (size_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t row = tile * 16 + rs;
+        const bool valid = row < rows;
+        Tile<MT> h[NHID + 1];
+        Tile<MT> dmul[NHID > 0 ? NHID : 1];   // relu' * dropout multiplier per hidden layer
+        h[0] = tile_load<MT>(valid ? e + row * H : nullptr, H, q);
+#pragma unroll
+        for (int k = 0; k < NHID; ++k) {
+            WFrag<MT> wf;
+            wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
+            const Tile<MT> o = tile_gemm(h[k], wf);
+            const ChanVec<MT> bv = chan_load<MT>(hp.hidB[k], H, q);
+            const DropCfg dc = drop_cfg(rng, stream_id0 + k, p, training);
+            const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o.v[m][r] + bv.v[m][r];
+                    float mul = v > 0.f ? 1.f : 0.f;
+                    if (dc.on) mul *= drop_mul(dc, rh, 16 * m + 4 * q + r);
+                    dmul[k].v[m][r] = mul;
+                    h[k + 1].v[m][r] = v * mul;
+                }
+            if (k + 1 < NHID) tile_store(valid ? h_stash + ((size_t)k * rows + row) * H : nullptr, H, q, h[k + 1]);
+        }
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l0 += h[NHID].v[m][r] * w2[0].v[m][r];
+                l1 += h[NHID].v[m][r] * w2[1].v[m][r];
+            }
+        l0 = redq(l0) + b2_0;
+        l1 = redq(l1) + b2_1;
+        float d0 = 0.f, d1 = 0.f;
+        if (valid) {
+            const bool masked = mask_invalid && cap[row / C] == 0.f;
+            if (!masked) {
+                if (has_loss) {
+                    const int y = (int)y_edges[row];
+                    const float mx = fmaxf(l0, l1);
+                    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+                    const float inv = 1.f / (e0 + e1);
+                    const float w = (y ? cw1 : cw0) * gl;
+                    d0 = w * (e0 * inv - (y == 0 ? 1.f : 0.f));
+                    d1 = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
+                }
+                if (dy_pred != nullptr) {
+                    if (voc == 1) d0 += dy_pred[row];
+                    else { d0 += dy_pred[row * 2]; d1 += dy_pred[row * 2 + 1]; }
+                }
+            }
+        }
+        if (q == 0) { db2a += d0; db2b += d1; }
+        Tile<MT> dh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dw2a.v[m][r] += d0 * h[NHID].v[m][r];
+                dw2b.v[m][r] += d1 * h[NHID].v[m][r];
+                dh.v[m][r] = d0 * w2[0].v[m][r] + d1 * w2[1].v[m][r];
+            }
+#pragma unroll
+        for (int k = NHID - 1; k >= 0; --k) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dh.v[m] *= dmul[k].v[m];
+            tile_store(valid ? dpre_stash + ((size_t)k * rows + row) * H : nullptr, H, q, dh);
+            WFrag<MT> wf;
+            wfrag_load_tr(wf, hp.hidW[k], H, rs, q);
+            dh = tile_gemm(dh, wf);
+        }
+        tile_store(valid ? de + row * H : nullptr, H, q, dh);
+    }
+    tile_red16(dw2a);
+    tile_red16(dw2b);
+    db2a = red16(db2a);
+    db2b = red16(db2b);
+    float* wp = wpartial + (size_t)wave * (size_t)((voc * H + voc + 3) & ~3);
+    if (rs == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int col = 16 * m + 4 * q;
+            if (col < H) {
+                *reinterpret_cast<f32x4*>(wp + col) = dw2a.v[m];
+                if (voc > 1) *reinterpret_cast<f32x4*>(wp + H + col) = dw2b.v[m];
+            }
+        }
+    }
+    if (lane == 0) {
+        wp[voc * H] = db2a;
+        if (voc > 1) wp[voc * H + 1] = db2b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding backward.  d w_e[h] = sum_rows cap[row / C] * de0[row][h]   (per-wavefront partials [nwaves][H])
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int C, int H, const float* __restrict__ cap,
+                                                              const float* __restrict__ de0, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    Tile<MT> acc;
+    tile_zero(acc);
+    const size_t ntiles = (rows + 15) / 16;
+    for (size_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t row = tile * 16 + rs;
+        const bool valid = row < rows;
+        const float cv = valid ? cap[row / C] : 0.f;
+        if (cv != 0.f) {
+            const Tile<MT> d = tile_load<MT>(de0 + row * H, H, q);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc.v[m] += d.v[m] * cv;
+        }
+    }
+    tile_red16(acc);
+    if (rs == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int col = 16 * m + 4 * q;
+            if (col < H) *reinterpret_cast<f32x4*>(partial + (size_t)wave * H + col) = acc.v[m];
+        }
+    }
+}
+
+// Node embedding backward, one workgroup per embedding row v (blockIdx.x < n_emb) plus one extra
+// workgroup (blockIdx.x == n_emb) for d w_c.  Fixed-order LDS tree, so reproducible.
+//   dEmb[v][h] = (1/C) * sum_{b,i} count_v(b,i) * sum_c dx0[b,i,c,h]
+//   d w_c[h]   = sum_{b,i,c} demand[b,c] * dx0[b,i,c,H/2+h]
+__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_nodes(int B, int V, int C, int H, int n_emb,
+                                                              const long long* __restrict__ x_nodes,
+                                                              const float* __restrict__ demand,
+                                                              const float* __restrict__ dx0,
+                                                              float* __restrict__ demb, float* __restrict__ dwc) {
+    extern __shared__ double lds_d[];     // [blockDim.x]
+    const int hh = H / 2;
+    const int v = blockIdx.x;
+    const int nbi = B * V;
+    // thread layout: tid = part * hh + h, parts = blockDim.x / hh
+    const int parts = blockDim.x / hh;
+    const int h = threadIdx.x % hh, part = threadIdx.x / hh;
+    double acc = 0;
+    if (part < parts) {
+        for (int bi = part; bi < nbi; bi += parts) {
+            if (v < n_emb) {
+                int cnt = 0;
+                for (int c = 0; c < C; ++c) {
+                    long long idx = x_nodes[(size_t)bi * C + c];
+                    idx = idx < 0 ? 0 : (idx >= n_emb ? n_emb - 1 : idx);
+                    cnt += (idx == v);
+                }
+                if (cnt) {
+                    float s = 0.f;
+                    for (int c = 0; c < C; ++c) s += dx0[((size_t)bi * C + c) * H + h];
+                    acc += (double)cnt * (double)s;
+                }
+            } else {
+                const int b = bi / V;
+                float s = 0.f;
+                for (int c = 0; c < C; ++c) s += demand[(size_t)b * C + c] * dx0[((size_t)bi * C + c) * H + hh + h];
+                acc += (double)s;
+            }
+        }
+    }
+    lds_d[threadIdx.x] = (part < parts) ? acc : 0.0;
+    __syncthreads();
+    if (part == 0) {
+        double s = 0;
+        for (int k = 0; k < parts; ++k) s += lds_d[k * hh + h];
+        if (v < n_emb) demb[(size_t)v * hh + h] = (float)(s / (double)C);
+        else dwc[h] = (float)s;
+    }
+}

@@ -1,0 +1,402 @@
+// Forward kernels of the residual gated graph-conv stack (gfx950).
+// Shapes: R_e = B*V*V*C edge rows laid out [B][V_i][V_j][C][H], R_n = B*V*C node rows [B][V][C][H].
+#pragma once
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// Embedding stage.  Mirrors ResidualGatedGCNModel.forward, src/gcn/models/gcn_model.py:68-84.
+//   e0[b,i,j,c,:] = cap[b,i,j] * w_e            x0[b,i,c,:H/2] = mean_c' Emb[x_nodes[b,i,c']]
+//                                               x0[b,i,c,H/2:] = demand[b,c] * w_c
+// ------------------------------------------------------------------------------------------------
+__global__ void k_embed_edges(size_t n4, int C, int H, const float* __restrict__ cap,
+                              const float* __restrict__ we, float* __restrict__ e0) {
+    const int h4 = H / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / h4;
+        const int col = (int)(i - row * h4) * 4;
+        const float cv = cap[row / C];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(we + col);
+        *reinterpret_cast<f32x4*>(e0 + row * H + col) = w * cv;
+    }
+}
+
+// one workgroup per (b, i); thread h < H/2 handles channel h of both halves
+__global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
+                              const float* __restrict__ demand, const float* __restrict__ emb,
+                              const float* __restrict__ wc, float* __restrict__ x0) {
+    const int bi = blockIdx.x;          // b*V + i
+    const int b = bi / V;
+    const int hh = H / 2;
+    for (int h = threadIdx.x; h < hh; h += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            long long idx = x_nodes[(size_t)bi * C + c];
+            idx = idx < 0 ? 0 : (idx >= n_emb ? n_emb - 1 : idx);
+            s += emb[(size_t)idx * hh + h];
+        }
+        const float mean = s / (float)C;
+        const float w = wc[h];
+        for (int c = 0; c < C; ++c) {
+            float* row = x0 + ((size_t)bi * C + c) * H;
+            row[h] = mean;
+            row[hh + h] = demand[(size_t)b * C + c] * w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node-side linears of one layer: Ux = x W_nU^T + b, Vn = x W_nV^T + b (NodeFeatures.forward,
+// src/gcn/models/gcn_layers.py:63-64) and Ve = x W_eV^T + b (EdgeFeatures.forward, :90).
+// One wavefront per 16-row tile.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_node_gemm3(
+    int rows, int H, const float* __restrict__ x,
+    const float* __restrict__ W0, const float* __restrict__ b0, float* __restrict__ y0,
+    const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ y1,
+    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ y2) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const int ntiles = (rows + 15) / 16;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int row = tile * 16 + rs;
+        const bool valid = row < rows;
+        const Tile<MT> in = tile_load<MT>(valid ? x + (size_t)row * H : nullptr, H, q);
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            const float* W = which == 0 ? W0 : (which == 1 ? W1 : W2);
+            const float* bias = which == 0 ? b0 : (which == 1 ? b1 : b2);
+            float* y = which == 0 ? y0 : (which == 1 ? y1 : y2);
+            WFrag<MT> wf;
+            wfrag_load_nt(wf, W, H, rs, q);
+            Tile<MT> out = tile_gemm(in, wf);
+            const ChanVec<MT> bv = chan_load<MT>(bias, H, q);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) out.v[m] += bv.v[m];
+            tile_store(valid ? y + (size_t)row * H : nullptr, H, q, out);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge pass 1 of a layer.  One wavefront per (b, i, c); it walks the 16-row j tiles of that
+// (b, i, c) slice (rows are C*H floats apart), and per tile does
+//   e_tmp = e_in W_U^T + b_U + Ve[b,i,c] + Ve[b,j,c]          (EdgeFeatures.forward, gcn_layers.py:89-93)
+//   gate  = sigmoid(e_tmp)                                     (:120)
+//   num  += gate * Vn[b,j,c] ; den += gate                     (NodeFeatures.forward, :65-69)
+// then x_tmp[b,i,c] = Ux + num / (1e-20 + den) ("mean") or Ux + num ("sum"), and per-wavefront partial
+// sums of e_tmp, e_tmp^2, x_tmp, x_tmp^2 per channel for the two BatchNorms (:122-123).
+// partial layout: [nwaves][4][H].
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_edge_fwd(
+    int B, int V, int C, int H, int mean_agg,
+    const float* __restrict__ e_in, const float* __restrict__ WU, const float* __restrict__ bU,
+    const float* __restrict__ Ve, const float* __restrict__ Vn, const float* __restrict__ Ux,
+    float* __restrict__ e_tmp, float* __restrict__ x_tmp, float* __restrict__ Aout, float* __restrict__ Dout,
+    float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    WFrag<MT> wf;
+    wfrag_load_nt(wf, WU, H, rs, q);
+    const ChanVec<MT> bu = chan_load<MT>(bU, H, q);
+    Tile<MT> s1, s2, sx1, sx2;
+    tile_zero(s1); tile_zero(s2); tile_zero(sx1); tile_zero(sx2);
+    const int units = B * V * C;
+    const int njt = (V + 15) / 16;
+    for (int u = wave; u < units; u += nwaves) {
+        const int b = u / (V * C);
+        const int rem = u - b * V * C;
+        const int i = rem / C;
+        const int c = rem - i * C;
+        const size_t nrow_i = (size_t)(b * V + i) * C + c;
+        ChanVec<MT> vei = chan_load<MT>(Ve + nrow_i * H, H, q);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) vei.v[m] += bu.v[m];
+        Tile<MT> num, den;
+        tile_zero(num); tile_zero(den);
+        for (int jt = 0; jt < njt; ++jt) {
+            const int j = jt * 16 + rs;
+            const bool valid = j < V;
+            const float vf = valid ? 1.f : 0.f;
+            const size_t erow = ((size_t)(b * V + i) * V + j) * C + c;
+            const size_t nrow_j = (size_t)(b * V + j) * C + c;
+            const Tile<MT> in = tile_load<MT>(valid ? e_in + erow * H : nullptr, H, q);
+            const Tile<MT> vej = tile_load<MT>(valid ? Ve + nrow_j * H : nullptr, H, q);
+            const Tile<MT> vnj = tile_load<MT>(valid ? Vn + nrow_j * H : nullptr, H, q);
+            Tile<MT> et = tile_gemm(in, wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                et.v[m] += vei.v[m] + vej.v[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = et.v[m][r];
+                    const float g = sigmoidf_(x) * vf;
+                    num.v[m][r] += g * vnj.v[m][r];
+                    den.v[m][r] += g;
+                    s1.v[m][r] += x * vf;
+                    s2.v[m][r] += x * x * vf;
+                }
+            }
+            tile_store(valid ? e_tmp + erow * H : nullptr, H, q, et);
+        }
+        tile_red16(num);
+        tile_red16(den);
+        if (rs == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int col = 16 * m + 4 * q;
+                if (col < H) {
+                    const f32x4 ux = *reinterpret_cast<const f32x4*>(Ux + nrow_i * H + col);
+                    f32x4 D, A;
+                    if (mean_agg) {
+                        D = den.v[m] + 1e-20f;
+                        A = num.v[m] / D;
+                    } else {
+                        D = f32x4{1.f, 1.f, 1.f, 1.f};
+                        A = num.v[m];
+                    }
+                    const f32x4 xt = ux + A;
+                    *reinterpret_cast<f32x4*>(x_tmp + nrow_i * H + col) = xt;
+                    *reinterpret_cast<f32x4*>(Aout + nrow_i * H + col) = A;
+                    *reinterpret_cast<f32x4*>(Dout + nrow_i * H + col) = D;
+                    sx1.v[m] += xt;
+                    sx2.v[m] += xt * xt;
+                }
+            }
+        }
+    }
+    tile_red16(s1);
+    tile_red16(s2);
+    if (rs == 0) {
+        float* p = partial + (size_t)wave * 4 * H;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int col = 16 * m + 4 * q;
+            if (col < H) {
+                *reinterpret_cast<f32x4*>(p + col) = s1.v[m];
+                *reinterpret_cast<f32x4*>(p + H + col) = s2.v[m];
+                *reinterpret_cast<f32x4*>(p + 2 * H + col) = sx1.v[m];
+                *reinterpret_cast<f32x4*>(p + 3 * H + col) = sx2.v[m];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column sums of a partial buffer [nP][ncols] in fp64, fixed order (thread t adds rows t, t+256, ...,
+// then a fixed LDS tree), so results do not depend on scheduling.  One workgroup per 4 columns.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_colsum4(const float* __restrict__ partial, int nP, int ncols, int col,
+                                              double out[4], double* lds /* [256*4] */) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int p = threadIdx.x; p < nP; p += blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)p * ncols + col);
+        a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+    }
+    lds[threadIdx.x * 4 + 0] = a0; lds[threadIdx.x * 4 + 1] = a1;
+    lds[threadIdx.x * 4 + 2] = a2; lds[threadIdx.x * 4 + 3] = a3;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds[threadIdx.x * 4 + k] += lds[(threadIdx.x + s) * 4 + k];
+        }
+        __syncthreads();
+    }
+    out[0] = lds[0]; out[1] = lds[1]; out[2] = lds[2]; out[3] = lds[3];
+    __syncthreads();
+}
+
+// partial [nP][4][H] (sum e, sum e^2, sum x, sum x^2) -> stats [4][H] = mean_e, rstd_e, mean_x, rstd_x.
+// Biased variance, eps 1e-5 (BatchNorm{2,3}d defaults, gcn_layers.py:10,30).  grid = 2 * H/4.
+__global__ __launch_bounds__(GCN_BLOCK) void k_bn_stats_finalize(const float* __restrict__ partial, int nP, int H,
+                                                                double n_e, double n_x, float* __restrict__ stats) {
+    __shared__ double lds[GCN_BLOCK * 4];
+    const int h4 = H / 4;
+    const int which = blockIdx.x / h4;            // 0 = edges, 1 = nodes
+    const int col = (blockIdx.x - which * h4) * 4;
+    double s1[4], s2[4];
+    block_colsum4(partial, nP, 4 * H, (2 * which) * H + col, s1, lds);
+    block_colsum4(partial, nP, 4 * H, (2 * which + 1) * H + col, s2, lds);
+    if (threadIdx.x == 0) {
+        const double n = which == 0 ? n_e : n_x;
+        for (int k = 0; k < 4; ++k) {
+            const double mean = s1[k] / n;
+            double var = s2[k] / n - mean * mean;
+            if (var < 0) var = 0;
+            stats[(2 * which) * H + col + k] = (float)mean;
+            stats[(2 * which + 1) * H + col + k] = (float)(1.0 / sqrt(var + (double)GCN_BN_EPS));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = dropout(relu(BN(tmp)) + resid)   (gcn_layers.py:122-128), rows x H, elementwise float4.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bn_apply(size_t rows, int H, const float* __restrict__ tmp, const float* __restrict__ resid,
+                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                           float* __restrict__ out, const unsigned long long* __restrict__ rng, int stream_id,
+                           float p, int training) {
+    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
+    const int h4 = H / 4;
+    const size_t n4 = rows * (size_t)h4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / h4;
+        const int col = (int)(i - row * h4) * 4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tmp + row * H + col);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(resid + row * H + col);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
+        f32x4 y = (t - mu) * rs * ga + be;
+        const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = (y[k] > 0.f ? y[k] : 0.f) + r[k];
+            if (dc.on) v *= drop_mul(dc, rh, col + k);
+            y[k] = v;
+        }
+        *reinterpret_cast<f32x4*>(out + row * H + col) = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge MLP head + loss partials.  MLP.forward (gcn_layers.py:167-176) with NHID = mlp_layers - 1
+// hidden Linear(H,H)+ReLU+Dropout blocks, then Linear(H, voc); optional -1e9 masking of zero-capacity
+// edges (gcn_model.py:97-110); loss_edges (model_utils.py:51-78): log_softmax over the 2 classes and
+// class-weighted NLL partial sums (sum w*nll, sum w); edge_error counters (model_utils.py:255-308)
+// per (b, c): #(pred == y and mask), #mask with mask = (y + pred) > 0.
+// hidW/hidB: NHID pointers each.  loss_partial: [nwaves][2].  counts: [2][B*C] int32 (zeroed by caller).
+// ------------------------------------------------------------------------------------------------
+struct HeadParams {
+    const float* hidW[3];
+    const float* hidB[3];
+    const float* outW;   // [voc][H]
+    const float* outB;   // [voc]
+};
+
+template <int MT, int NHID>
+__global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ e,
+    const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
+    const float* __restrict__ edge_cw, float* __restrict__ logits, float* __restrict__ loss_partial,
+    int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const size_t ntiles = (rows + 15) / 16;
+    const int BC_stride = V * V * C;
+    ChanVec<MT> w2[2];
+    w2[0] = chan_load<MT>(hp.outW, H, q);
+    w2[1] = chan_load<MT>(voc > 1 ? hp.outW + H : nullptr, H, q);
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    float acc_wn = 0.f, acc_w = 0.f;
+    for (size_t tile = wave; tile < ntiles; tile += nwaves) {
+        const size_t row = tile * 16 + rs;
+        const bool valid = row < rows;
+        Tile<MT> h = tile_load<MT>(valid ? e + row * H : nullptr, H, q);
+#pragma unroll
+        for (int k = 0; k < NHID; ++k) {
+            WFrag<MT> wf;
+            wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
+            Tile<MT> o = tile_gemm(h, wf);
+            const ChanVec<MT> bv = chan_load<MT>(hp.hidB[k], H, q);
+            const DropCfg dc = drop_cfg(rng, stream_id0 + k, p, training);
+            const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = o.v[m][r] + bv.v[m][r];
+                    v = v > 0.f ? v : 0.f;
+                    if (dc.on) v *= drop_mul(dc, rh, 16 * m + 4 * q + r);
+                    h.v[m][r] = v;
+                }
+        }
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l0 += h.v[m][r] * w2[0].v[m][r];
+                l1 += h.v[m][r] * w2[1].v[m][r];
+            }
+        l0 = redq(l0) + b2_0;
+        l1 = redq(l1) + b2_1;
+        if (valid && q == 0) {
+            if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+            if (voc == 1) {
+                logits[row] = l0;
+            } else {
+                logits[row * 2] = l0;
+                logits[row * 2 + 1] = l1;
+                if (y_edges != nullptr) {
+                    const int y = (int)y_edges[row];
+                    const float mx = fmaxf(l0, l1);
+                    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+                    const float logp = (y ? l1 : l0) - lse;
+                    const float w = y ? cw1 : cw0;
+                    acc_wn += -w * logp;
+                    acc_w += w;
+                    const int pred = l1 > l0 ? 1 : 0;
+                    if (y + pred > 0) {
+                        const int b = (int)(row / BC_stride), c = (int)(row % C);
+                        const int BC = (int)(rows / BC_stride) * C;
+                        atomicAdd(&counts[BC + b * C + c], 1);
+                        if (pred == y) atomicAdd(&counts[b * C + c], 1);
+                    }
+                }
+            }
+        }
+    }
+    if (loss_partial != nullptr) {
+        // lanes with q != 0 hold zeros; sum the 16 row slots of quarter 0
+        acc_wn = red16(acc_wn);
+        acc_w = red16(acc_w);
+        if (lane == 0) {
+            loss_partial[(size_t)wave * 2] = acc_wn;
+            loss_partial[(size_t)wave * 2 + 1] = acc_w;
+        }
+    }
+}
+
+// loss = sum(w*nll) / sum(w); edge error = 100 * (1 - mean_{b,c} correct/mask) (0/0 -> NaN as in the
+// reference).  out[0] = loss, out[1] = sum w, out[2] = edge error %, flags[b*C+c] = acc < 1.
+__global__ __launch_bounds__(GCN_BLOCK) void k_loss_finalize(const float* __restrict__ loss_partial, int nP,
+                                                            const int* __restrict__ counts, int BC,
+                                                            float* __restrict__ out, unsigned char* __restrict__ flags) {
+    __shared__ double lds[GCN_BLOCK * 2];
+    double a = 0, w = 0;
+    for (int p = threadIdx.x; p < nP; p += blockDim.x) { a += loss_partial[(size_t)p * 2]; w += loss_partial[(size_t)p * 2 + 1]; }
+    double accsum = 0;
+    for (int k = threadIdx.x; k < BC; k += blockDim.x) {
+        const float acc = (float)counts[k] / (float)counts[BC + k];
+        flags[k] = acc < 1.0f ? 1 : 0;
+        accsum += (double)acc;
+    }
+    lds[threadIdx.x * 2] = a; lds[threadIdx.x * 2 + 1] = w;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2]; lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1]; }
+        __syncthreads();
+    }
+    const double tot_a = lds[0], tot_w = lds[1];
+    __syncthreads();
+    lds[threadIdx.x * 2] = accsum;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(tot_a / tot_w);
+        out[1] = (float)tot_w;
+        out[2] = (float)(100.0 * (1.0 - lds[0] / (double)BC));
+    }
+}

@@ -1,0 +1,179 @@
+"""ctypes binding of libgcn_uelb_hip.so (the C ABI declared in include/gcn_uelb_hip.h).
+
+PyTorch is used for device memory and streams only; every computation of the hot path runs in the
+hand-written gfx950 kernels behind these entry points.  There is no fallback: if the library is
+missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
+ABI_VERSION = 1
+MAX_H = 64
+LAYER_NPARAMS = 12
+
+
+class GcnHipError(RuntimeError):
+    pass
+
+
+class ModelDesc(ctypes.Structure):
+    """Mirror of ``gcn_model_desc`` (include/gcn_uelb_hip.h)."""
+    _fields_ = [
+        ("B", c_int), ("V", c_int), ("C", c_int), ("H", c_int), ("L", c_int),
+        ("mlp_layers", c_int), ("voc_out", c_int), ("n_emb", c_int), ("aggregation", c_int),
+        ("training", c_int), ("mask_invalid_edges", c_int), ("has_labels", c_int),
+        ("p_layer", c_float), ("p_mlp", c_float),
+    ]
+
+
+_lib = None
+
+
+def _declare(lib):
+    lib.gcn_abi_version.restype = c_int
+    lib.gcn_last_error.restype = c_char_p
+    for name in ("gcn_layer_saved_floats", "gcn_layer_ws_bytes"):
+        fn = getattr(lib, name)
+        fn.restype = c_size_t
+        fn.argtypes = [c_int, c_int, c_int, c_int]
+    lib.gcn_layer_fwd.restype = c_int
+    lib.gcn_layer_fwd.argtypes = [c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]
+    lib.gcn_layer_bwd.restype = c_int
+    lib.gcn_layer_bwd.argtypes = [c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int,
+                                  c_void_p, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_void_p,
+                                  POINTER(c_void_p), c_void_p, c_size_t, c_void_p]
+    lib.gcn_model_num_params.restype = c_int
+    lib.gcn_model_num_params.argtypes = [POINTER(ModelDesc)]
+    for name in ("gcn_model_saved_floats", "gcn_model_ws_bytes"):
+        fn = getattr(lib, name)
+        fn.restype = c_size_t
+        fn.argtypes = [POINTER(ModelDesc)]
+    lib.gcn_model_fwd.restype = c_int
+    lib.gcn_model_fwd.argtypes = [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.gcn_model_bwd.restype = c_int
+    lib.gcn_model_bwd.argtypes = [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  POINTER(c_void_p), c_void_p, c_size_t, c_void_p]
+    if hasattr(lib, "gcn_edge_error"):
+        lib.gcn_edge_error.restype = c_int
+        lib.gcn_edge_error.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    if hasattr(lib, "gcn_beam_search"):
+        lib.gcn_beam_search.restype = c_int
+        lib.gcn_beam_search.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        lib.gcn_beam_ws_bytes.restype = c_size_t
+        lib.gcn_beam_ws_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    if hasattr(lib, "gcn_beam_scores"):
+        lib.gcn_beam_scores.restype = c_int
+        lib.gcn_beam_scores.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    if hasattr(lib, "gcn_load_factor"):
+        lib.gcn_load_factor.restype = c_int
+        lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]
+
+
+def load():
+    """Load the shared library (once).  Raises GcnHipError if it is missing or of another ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GcnHipError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                              f"(hipcc --offload-arch=gfx950); there is no fallback path")
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        if lib.gcn_abi_version() != ABI_VERSION:
+            raise GcnHipError(f"ABI mismatch: library {lib.gcn_abi_version()} vs binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gcn_last_error().decode("utf-8", "replace")
+        raise GcnHipError(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise GcnHipError(f"{name} is on {t.device}: the gfx950 HIP path needs tensors on a ROCm GPU "
+                          f"(there is no CPU fallback; use the oracle under oracle/ for CPU checks)")
+
+
+def f32c(t, name):
+    """Contiguous fp32 view/copy of a tensor on its device."""
+    require_cuda(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# workspace and dropout-state management (plumbing)
+# ------------------------------------------------------------------------------------------------
+_ws = {}
+_rng = {}
+
+
+def workspace(device, nbytes):
+    """A per-device scratch buffer, grown on demand.  Calls that share it must be stream-ordered
+    (they are: one host thread per device, current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if torch.cuda.is_current_stream_capturing():
+        # memory used inside a captured graph must stay valid for every replay: give each capture its own
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def rng_state(device):
+    """Device-resident {seed, step} words read by the dropout code of the kernels."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    st = _rng.get(key)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        _rng[key] = st
+    return st
+
+
+def reseed(seed, device=None):
+    """Restart the dropout stream (all devices if device is None)."""
+    for key, st in list(_rng.items()):
+        if device is None or key == device.index:
+            st.copy_(torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def next_rng_snapshot(device):
+    """Advance the step word and return a private copy {seed, step} for one forward/backward pair."""
+    st = rng_state(device)
+    st[1:2].add_(1)
+    return st.clone()

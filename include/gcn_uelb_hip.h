@@ -1,0 +1,114 @@
+/*
+ * C ABI of libgcn_uelb_hip.so: hand-written gfx950 (MI355X) kernels for the GCN hot path of
+ * Shota-OSD/graph-convnet-uelb.  The reference is pure Python/PyTorch and has no FFI of its own;
+ * each entry point below names the reference function(s) it replaces (paths relative to the
+ * reference checkout).  The Python classes that keep the reference's nn.Module / factory API call
+ * these through ctypes (graph-convnet-uelb_amd/src/gcn/hip/lib.py).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host"; tensors are contiguous,
+ *    fp32 ("float") or int64 ("long long"), laid out exactly as the reference's tensors:
+ *      node tensors [B][V][C][H], edge tensors [B][V_i][V_j][C][H], H fastest.
+ *  - the library allocates nothing: the caller owns every buffer, including `saved` (activations
+ *    kept for backward) and `ws` (scratch); the *_floats / *_bytes queries give the sizes.
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises.
+ *  - return value 0 = ok, negative = error; gcn_last_error() returns the message for the calling
+ *    thread.  One host thread per device; calls that share buffers must be stream-ordered.
+ *  - H must be a multiple of 4 and <= GCN_MAX_H.
+ *  - `rng` points at two 64-bit words {seed, step} in device memory, read by the dropout code at
+ *    execution time (so a captured HIP graph sees the step it is replayed with).  May be NULL when
+ *    training == 0.
+ */
+#ifndef GCN_UELB_HIP_H
+#define GCN_UELB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCN_ABI_VERSION 1
+#define GCN_MAX_H 64
+#define GCN_LAYER_NPARAMS 12
+#define GCN_MAX_MLP_LAYERS 4
+
+int gcn_abi_version(void);
+const char* gcn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * One residual gated graph-conv layer.
+ * Replaces ResidualGatedGCNLayer.forward (src/gcn/models/gcn_layers.py:108-129), i.e.
+ * EdgeFeatures.forward (:81-94), NodeFeatures.forward (:55-70), BatchNormEdge/BatchNormNode
+ * (:5-43), ReLU + residual + Dropout (:124-128), and what autograd derives from them.
+ *
+ * params[12], in the reference's state_dict order:
+ *   node_feat.U.weight, node_feat.U.bias, node_feat.V.weight, node_feat.V.bias,
+ *   edge_feat.U.weight, edge_feat.U.bias, edge_feat.V.weight, edge_feat.V.bias,
+ *   bn_node.batch_norm.weight, bn_node.batch_norm.bias, bn_edge.batch_norm.weight, bn_edge.batch_norm.bias
+ * aggregation: 0 = "sum", 1 = "mean".  stream_id: distinguishes dropout streams (use the layer index).
+ * ---------------------------------------------------------------------------------------------- */
+size_t gcn_layer_saved_floats(int B, int V, int C, int H);
+size_t gcn_layer_ws_bytes(int B, int V, int C, int H);
+
+int gcn_layer_fwd(int B, int V, int C, int H, int aggregation, float p_drop, int training,
+                  const unsigned long long* rng, int stream_id,
+                  const float* x_in, const float* e_in, const float* const* params /* host array of 12 device ptrs */,
+                  float* x_out, float* e_out, float* saved, void* ws, size_t ws_bytes, void* stream);
+
+/* dx / de hold d loss / d x_out, d e_out on entry and d loss / d x_in, d e_in on return.
+ * grads[12] (host array of device pointers, same order as params) are overwritten, not accumulated. */
+int gcn_layer_bwd(int B, int V, int C, int H, int aggregation, float p_drop, int training,
+                  const unsigned long long* rng, int stream_id,
+                  const float* x_in, const float* e_in, const float* const* params, const float* saved,
+                  float* dx, float* de, float* const* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole model: embedding -> L layers -> edge MLP -> (masking) -> loss and edge-error counters.
+ * Replaces ResidualGatedGCNModel.forward (src/gcn/models/gcn_model.py:45-123), MLP.forward
+ * (src/gcn/models/gcn_layers.py:167-176), loss_edges (src/gcn/models/model_utils.py:51-78) and
+ * edge_error (:255-308), plus their autograd backward (src/gcn/training/supervised_strategy.py:94-95).
+ *
+ * params / grads: host arrays of gcn_model_num_params() device pointers in the reference's
+ * state_dict order: nodes_embedding.weight, commodities_embedding.weight,
+ * edges_values_embedding.weight, 12 per layer (as above), then mlp_edges.layers.{0,3,..}.weight/.bias
+ * pairs, mlp_edges.output_layer.weight, mlp_edges.output_layer.bias.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gcn_model_desc {
+    int B, V, C, H, L;
+    int mlp_layers;          /* linear layers in the edge MLP, 1..GCN_MAX_MLP_LAYERS */
+    int voc_out;             /* 1 (edge scores) or 2 (two-class logits) */
+    int n_emb;               /* rows of nodes_embedding (3*C in the reference) */
+    int aggregation;         /* 0 sum, 1 mean */
+    int training;            /* dropout active */
+    int mask_invalid_edges;  /* logits of zero-capacity edges := -1e9 */
+    int has_labels;          /* y_edges / edge_cw given: compute loss and edge-error counters (voc_out == 2) */
+    float p_layer;           /* dropout of the conv layers (reference ctor default 0.3) */
+    float p_mlp;             /* dropout of the MLP (0.2) */
+} gcn_model_desc;
+
+int gcn_model_num_params(const gcn_model_desc* d);
+size_t gcn_model_saved_floats(const gcn_model_desc* d);
+size_t gcn_model_ws_bytes(const gcn_model_desc* d);
+
+/* y_pred: [B,V,V,C,voc_out].  loss_out[4] = {loss, sum of class weights, edge error %, 0}.
+ * err_counts: int32 [2][B*C] (correct, mask) scratch owned by the caller; err_flags: uint8 [B*C],
+ * 1 where the (b, c) slice is not perfectly predicted.  Both may be NULL when has_labels == 0. */
+int gcn_model_fwd(const gcn_model_desc* d, const float* cap, const float* demand, const long long* x_nodes,
+                  const long long* y_edges, const float* edge_cw, const float* const* params,
+                  const unsigned long long* rng, float* y_pred, float* loss_out, int* err_counts,
+                  unsigned char* err_flags, float* saved, void* ws, size_t ws_bytes, void* stream);
+
+/* dloss: device scalar, upstream gradient of the loss (NULL = 1).  dy_pred: upstream gradient of
+ * y_pred, [B,V,V,C,voc_out] (NULL = 0).  grads are overwritten. */
+int gcn_model_bwd(const gcn_model_desc* d, const float* cap, const float* demand, const long long* x_nodes,
+                  const long long* y_edges, const float* edge_cw, const float* const* params,
+                  const unsigned long long* rng, const float* saved, const float* loss_out,
+                  const float* dloss, const float* dy_pred, float* const* grads,
+                  void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

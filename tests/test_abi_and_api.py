@@ -1,0 +1,81 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, and the
+drop-in Python classes keep the reference's names, state_dict keys and error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_files, load_golden
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "gcn_uelb_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from src.gcn.hip import lib as L
+    lib = L.load()
+    names = _header_functions()
+    assert "gcn_model_fwd" in names and "gcn_layer_bwd" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gcn_uelb_hip.h but not exported"
+    assert lib.gcn_abi_version() == L.ABI_VERSION
+
+
+def test_size_queries_and_argument_errors_without_gpu():
+    from src.gcn.hip import lib as L
+    lib = L.load()
+    assert lib.gcn_layer_saved_floats(2, 5, 3, 8) == 2 * 5 * 5 * 3 * 8 + 4 * 2 * 5 * 3 * 8 + 32
+    assert lib.gcn_layer_ws_bytes(2, 5, 3, 8) > 0
+    assert lib.gcn_layer_saved_floats(2, 5, 3, 6) == 0            # H % 4 != 0
+    assert b"multiple of 4" in lib.gcn_last_error()
+    d = L.ModelDesc(B=2, V=5, C=3, H=8, L=2, mlp_layers=9, voc_out=2, n_emb=9, aggregation=1)
+    assert lib.gcn_model_num_params(ctypes.byref(d)) == -1
+    assert b"mlp_layers" in lib.gcn_last_error()
+    d.mlp_layers = 2
+    assert lib.gcn_model_num_params(ctypes.byref(d)) == 3 + 12 * 2 + 4
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def test_model_state_dict_keys_match_reference():
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    g = load_golden([p for p in golden_files("model") if p.endswith("model_h12_mlp3.npz")][0])
+    cfg = _Cfg(num_nodes=6, num_commodities=4, voc_edges_in=3, voc_edges_out=2, hidden_dim=12, num_layers=2,
+               mlp_layers=3, aggregation="mean")
+    model = ResidualGatedGCNModel(cfg, torch.float32, torch.long)
+    ref_keys = [k[len("param."):] for k in g if k.startswith("param.")]
+    assert list(model.state_dict().keys()) == ref_keys
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == g["param." + k].shape
+    assert [p.data_ptr() for p in model.hip_parameters()] == [v.data_ptr() for v in model.state_dict().values()]
+    for attr in ("num_nodes", "num_commodities", "hidden_dim", "num_layers", "mlp_layers", "aggregation",
+                 "voc_edges_out", "dropout_rate"):
+        assert hasattr(model, attr)
+
+
+def test_model_errors_match_reference_behaviour():
+    from src.gcn.hip.lib import GcnHipError
+    from src.gcn.models.gcn_layers import MLP, ResidualGatedGCNLayer
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    cfg = _Cfg(num_nodes=5, num_commodities=3, voc_edges_in=3, voc_edges_out=2, hidden_dim=8, num_layers=1,
+               mlp_layers=2, aggregation="mean")
+    model = ResidualGatedGCNModel(cfg, torch.float32, torch.long)
+    cap = torch.zeros(2, 5, 5)
+    with pytest.raises(ValueError):        # gcn_model.py:115-116
+        model(cap.long(), torch.zeros(2, 3), cap, torch.zeros(2, 5, 3, dtype=torch.long))
+    with pytest.raises(GcnHipError):       # no silent CPU fallback
+        model(cap.long(), torch.zeros(2, 3), cap, torch.zeros(2, 5, 3, dtype=torch.long), compute_loss=False)
+    with pytest.raises(ValueError):        # gcn_layers.py:153-154
+        MLP(8, 2, num_layers=3, hidden_dims=[8])
+    layer = ResidualGatedGCNLayer(8, "mean", dropout_rate=0.0)
+    assert len(layer.hip_parameters()) == 12
+    with pytest.raises(GcnHipError):
+        layer(torch.zeros(1, 2, 1, 8), torch.zeros(1, 2, 2, 1, 8))
