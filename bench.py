@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the GCN hot path on MI355X: training graphs/sec (forward + backward).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N > 1 through torch.distributed.run); every rank runs the
+workload on its own synthetic batch (weak scaling), gradients are averaged with one RCCL all-reduce of
+the flat gradient buffer per step.  A "step" is one forward + backward of the full model (embedding,
+L gated graph-conv layers, edge MLP, loss, all parameter gradients) over one batch that is already
+resident in HBM; data loading and the optimizer are excluded, as in the metric's definition.
+Rank 0 prints ONE JSON line.
+
+Besides the headline value the line carries
+  roofline     - the dominant kernel's algorithmic bytes per launch / its average duration, measured
+                 with HIP events around each of its launches in an eager (non-graph) pass;
+  cpu_baseline - the CPU oracle (oracle/gcn_oracle.py, a plain PyTorch restatement of the reference)
+                 timed on this box's host cores on the same batch, rank 0, N = 1 only;
+  beam_search  - graphs/sec of the batched GPU beam-search decode next to the C oracle (N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "graph-convnet-uelb_amd"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (spec)
+DOMINANT_KERNEL = "k_edge_bwd_main"
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build_model(shape, device):
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
+              hidden_dim=shape["H"], num_layers=shape["L"], mlp_layers=2, aggregation="mean", dropout_rate=0.5)
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    return ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(device)
+
+
+def cpu_baseline(shape, batch, max_seconds=25.0):
+    """fwd+bwd of the CPU oracle in train mode (dropout on, as the trainer runs) on the same batch."""
+    from oracle import gcn_oracle
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
+              hidden_dim=shape["H"], num_layers=shape["L"], mlp_layers=2, aggregation="mean")
+    torch.manual_seed(0)
+    ref = ResidualGatedGCNModel(cfg, torch.float32, torch.long)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
+    ocfg = dict(num_layers=shape["L"], mlp_layers=2, aggregation="mean", voc_edges_out=2)
+    cap = torch.from_numpy(batch["edges_capacity"])
+    comm = torch.from_numpy(batch["commodities"])
+    x_nodes = torch.from_numpy(batch["nodes"])
+    y_edges = torch.from_numpy(batch["edges_target"])
+    cores = torch.get_num_threads()
+
+    def one():
+        for p in P.values():
+            p.grad = None
+        _, loss = gcn_oracle.model_forward(P, ocfg, cap, comm, x_nodes, y_edges, batch["edge_cw"], training=True)
+        loss.backward()
+
+    one()                                     # warm-up
+    times = []
+    t_end = time.time() + max_seconds
+    while len(times) < 5 and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        one()
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": round(shape["B"] / med, 3), "unit": "graphs/s", "cores": int(cores), "kind": "port",
+            "ms_per_step": round(med * 1e3, 2),
+            "sample": f"{len(times)} fwd+bwd steps of the same B={shape['B']} batch, train mode (dropout on), "
+                      f"plain-PyTorch CPU oracle, torch threads={cores}"}
+
+
+def beam_bench(shape, batch, device, K=10):
+    """Deterministic strict beam search (the evaluator's setting, K = beam_size of the config) on the
+    logits of the benchmark model: GPU kernel vs the C oracle on one host core."""
+    from oracle import beam_oracle_c
+    from src.gcn.algorithms.beamsearch_uelb import BeamSearchFactory
+    B, V, C = shape["B"], shape["V"], shape["C"]
+    g = torch.Generator().manual_seed(7)
+    logits = (torch.randn((B, V, V, C, 2), generator=g) * 2.0).to(device)
+    cap = torch.from_numpy(batch["edges_capacity"]).to(device)
+    comm = torch.from_numpy(batch["commodities"]).to(device)
+    algo = BeamSearchFactory.create_algorithm("deterministic", y_pred_edges=logits, beam_size=K, batch_size=B,
+                                              edges_capacity=cap, commodities=comm, dtypeFloat=torch.float32,
+                                              dtypeLong=torch.long, mode_strict=True)
+    algo.search()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.time()
+    for _ in range(reps):
+        paths, plen, feas, att = algo._run()
+    torch.cuda.synchronize()
+    gpu_s = (time.time() - t0) / reps
+    y = algo.y.cpu().numpy()
+    t0 = time.time()
+    rp, rl, rf, _, _ = beam_oracle_c.search(y, batch["edges_capacity"], batch["commodities"], K, "deterministic", True)
+    cpu_s = time.time() - t0
+    same = bool(np.array_equal(paths.cpu().numpy(), rp) and np.array_equal(plen.cpu().numpy(), rl))
+    return {"algorithm": "deterministic", "beam_size": K, "mode_strict": True, "graphs_per_s": round(B / gpu_s, 1),
+            "ms_per_batch": round(gpu_s * 1e3, 3), "cpu_oracle_graphs_per_s": round(B / cpu_s, 1), "cpu_cores": 1,
+            "paths_bit_exact_vs_oracle": same}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="nsfnet_10_commodities")
+    ap.add_argument("--batch", type=int, default=0, help="graphs per GPU (default: the config's batch_size)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-beam", action="store_true")
+    args = ap.parse_args()
+
+    from src.common.synthetic import CONFIGS, make_batch
+    from src.gcn.hip import lib as L
+    from src.gcn.hip.train_step import HipTrainStep
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    shape = dict(CONFIGS[args.config])
+    if args.batch:
+        shape["B"] = args.batch
+    B, V, C, H, Lr = shape["B"], shape["V"], shape["C"], shape["H"], shape["L"]
+    batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
+                       seed=1234 + rank)
+    model = build_model(shape, device).train()          # train mode: dropout active, as the trainer runs
+    if dist is not None:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    step = HipTrainStep(model, B, device, use_graph=not args.no_graph)
+    step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
+                    batch["edges_target"], batch["edge_cw"])
+    inv_world = 1.0 / world
+
+    def one_step():
+        step.step()
+        if dist is not None:
+            dist.all_reduce(step.flat_grad)
+            step.flat_grad.mul_(inv_world)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(step.loss_out[0].item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- dominant kernel, timed with HIP events around each of its launches (eager pass, rank 0)
+    roofline = None
+    if rank == 0:
+        lib = L.load()
+        eager = HipTrainStep(model, B, device, use_graph=False)
+        eager.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
+                         batch["edges_target"], batch["edge_cw"])
+        for _ in range(3):
+            eager.step()
+        torch.cuda.synchronize()
+        lib.gcn_prof_begin(DOMINANT_KERNEL.encode())
+        nprof = max(5, min(args.steps, 20))
+        for _ in range(nprof):
+            eager.step()
+        tot_ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        lib.gcn_prof_end(ctypes.byref(tot_ms), ctypes.byref(n))
+        avg_ms = tot_ms.value / max(n.value, 1)
+        Re, Rn = B * V * V * C, B * V * C
+        # one launch = the edge backward of one layer: read d e_new, read the saved activation, write d e_in
+        algo_bytes = 12.0 * H * (Re + Rn)
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        step_bytes = (20.0 * Lr + 20.0) * H * Re
+        roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "launches_timed": int(n.value),
+                    "whole_step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)}
+        for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore
+            p.grad = gview
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "GCN train graphs/sec (fwd+bwd)", "value": round(value, 1), "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs/gcn/{args.config}.json: V={V} C={C} H={H} L={Lr} mlp_layers=2 mean "
+                                   f"aggregation, {B} graphs per GPU, train mode (dropout 0.3/0.2 on), fwd+bwd, "
+                                   f"{'HIP graph replay' if not args.no_graph else 'eager launches'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "loss": round(loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.skip_cpu:
+            out["cpu_baseline"] = cpu_baseline(shape, batch)
+        if world == 1 and not args.skip_beam:
+            try:
+                out["beam_search"] = beam_bench(shape, batch, device)
+            except Exception as ex:      # the headline metric must still be reported
+                out["beam_search"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

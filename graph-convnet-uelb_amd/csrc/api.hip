@@ -6,8 +6,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "../../include/gcn_uelb_hip.h"
+#include "beam.hpp"
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
 
@@ -23,11 +26,38 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- optional per-kernel timing with HIP events (used by bench.py; off by default) -----------------
+// gcn_prof_begin(substr) arms it: every later launch whose name contains substr is bracketed by two
+// events on its own stream.  gcn_prof_end() synchronises those events and returns the summed time.
+struct ProfState {
+    bool on = false;
+    char match[64] = "";
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    hipEvent_t pending = nullptr;
+};
+ProfState g_prof;
+
+inline void prof_pre(const char* name, hipStream_t st) {
+    if (!g_prof.on || strstr(name, g_prof.match) == nullptr) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, st);
+    g_prof.ev.emplace_back(a, b);
+    g_prof.pending = b;
+}
+inline void prof_post(hipStream_t st) {
+    if (g_prof.pending) { (void)hipEventRecord(g_prof.pending, st); g_prof.pending = nullptr; }
+}
+
+#define GCN_PROF_PRE(name) prof_pre(name, (hipStream_t)GCN_STREAM)
 #define GCN_CHECK_LAUNCH(name)                                                                   \
     do {                                                                                         \
+        prof_post((hipStream_t)GCN_STREAM);                                                      \
         hipError_t e_ = hipGetLastError();                                                       \
         if (e_ != hipSuccess) return fail(-3, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
+
+#define GCN_STREAM st
 
 struct Dims {
     int B, V, C, H;
@@ -150,19 +180,24 @@ int layer_fwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
                 const float* x_in, const float* e_in, const float* const* P, float* x_out, float* e_out,
                 const LayerSaved& S, const LayerFwdWs& W, hipStream_t st) {
     const int H = d.H;
+    GCN_PROF_PRE("k_node_gemm3");
     k_node_gemm3<MT><<<wave_blocks((d.Rn + 15) / 16), GCN_BLOCK, 0, st>>>(
         (int)d.Rn, H, x_in, P[0], P[1], W.Ux, P[2], P[3], S.Vn, P[6], P[7], W.Ve);
     GCN_CHECK_LAUNCH("k_node_gemm3");
+    GCN_PROF_PRE("k_edge_fwd");
     k_edge_fwd<MT><<<W.nblk, GCN_BLOCK, 0, st>>>(d.B, d.V, d.C, H, agg, e_in, P[4], P[5], W.Ve, S.Vn, W.Ux,
                                                  S.e_tmp, S.x_tmp, S.A, S.D, W.partial);
     GCN_CHECK_LAUNCH("k_edge_fwd");
+    GCN_PROF_PRE("k_bn_stats_finalize");
     k_bn_stats_finalize<<<2 * (H / 4), GCN_BLOCK, 0, st>>>(W.partial, W.nblk * GCN_WAVES_PER_BLOCK, H, (double)d.Re,
                                                            (double)d.Rn, S.stats);
     GCN_CHECK_LAUNCH("k_bn_stats_finalize");
+    GCN_PROF_PRE("k_bn_apply(edges)");
     k_bn_apply<<<elem_blocks(d.Re * (H / 4)), 256, 0, st>>>(d.Re, H, S.e_tmp, e_in, S.stats, S.stats + H, P[10], P[11],
                                                             e_out, rng, 2 * sid, p, training);
     GCN_CHECK_LAUNCH("k_bn_apply(edges)");
     if (x_out != nullptr) {
+        GCN_PROF_PRE("k_bn_apply(nodes)");
         k_bn_apply<<<elem_blocks(d.Rn * (H / 4)), 256, 0, st>>>(d.Rn, H, S.x_tmp, x_in, S.stats + 2 * H, S.stats + 3 * H,
                                                                 P[8], P[9], x_out, rng, 2 * sid + 1, p, training);
         GCN_CHECK_LAUNCH("k_bn_apply(nodes)");
@@ -175,27 +210,34 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
                 const float* x_in, const float* e_in, const float* const* P, const LayerSaved& S, float* dx,
                 float* de, float* const* G, const LayerBwdWs& W, hipStream_t st) {
     const int H = d.H;
+    GCN_PROF_PRE("k_bn_bwd_stats(edges)");
     k_bn_bwd_stats<MT><<<W.nblk_e, GCN_BLOCK, 0, st>>>(d.Re, H, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11],
                                                        W.bpart_e, rng, 2 * sid, p, training);
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(edges)");
+    GCN_PROF_PRE("k_bn_bwd_stats(nodes)");
     k_bn_bwd_stats<MT><<<W.nblk_x, GCN_BLOCK, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9],
                                                        W.bpart_x, rng, 2 * sid + 1, p, training);
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
+    GCN_PROF_PRE("k_bn_bwd_finalize(edges)");
     k_bn_bwd_finalize<<<H / 4, GCN_BLOCK, 0, st>>>(W.bpart_e, W.nblk_e * GCN_WAVES_PER_BLOCK, H, (double)d.Re, W.bstats_e,
                                                    G[10], G[11]);
     GCN_CHECK_LAUNCH("k_bn_bwd_finalize(edges)");
+    GCN_PROF_PRE("k_bn_bwd_finalize(nodes)");
     k_bn_bwd_finalize<<<H / 4, GCN_BLOCK, 0, st>>>(W.bpart_x, W.nblk_x * GCN_WAVES_PER_BLOCK, H, (double)d.Rn, W.bstats_x,
                                                    G[8], G[9]);
     GCN_CHECK_LAUNCH("k_bn_bwd_finalize(nodes)");
+    GCN_PROF_PRE("k_node_bwd_pre");
     k_node_bwd_pre<<<elem_blocks(d.Rn * (H / 4)), 256, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.D, S.stats + 2 * H, S.stats + 3 * H,
                                                                 P[8], P[9], W.bstats_x, dx, W.dxtmp, W.qv, rng, 2 * sid + 1,
                                                                 p, training);
     GCN_CHECK_LAUNCH("k_node_bwd_pre");
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
+    GCN_PROF_PRE("k_edge_bwd_main");
     k_edge_bwd_main<MT><<<wave_blocks(units), GCN_BLOCK, 0, st>>>(d.B, d.V, d.C, H, d.IT, agg, de, S.e_tmp, P[4], S.Vn, S.A, W.qv,
                                                                   S.stats, P[10], P[11], W.bstats_e, W.det, W.rowpart,
                                                                   W.colVe, W.colVn, rng, 2 * sid, p, training);
     GCN_CHECK_LAUNCH("k_edge_bwd_main");
+    GCN_PROF_PRE("k_node_bwd");
     k_node_bwd<MT><<<wave_blocks((d.Rn + 15) / 16), GCN_BLOCK, 0, st>>>((int)d.Rn, H, d.njt, d.nit, W.rowpart, W.colVe,
                                                                        W.colVn, W.dxtmp, P[0], P[2], P[6], dx, W.dVe, W.dVn);
     GCN_CHECK_LAUNCH("k_node_bwd");
@@ -203,16 +245,19 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     {
         TnProblems pr = {};
         pr.X[0] = W.det; pr.Y[0] = e_in;
+        GCN_PROF_PRE("k_gemm_tn(edges)");
         k_gemm_tn<MT><<<dim3(W.S_e, (MT + 3) / 4, 1), GCN_BLOCK, 0, st>>>(d.Re, H, 1, pr, W.tn_e);
         GCN_CHECK_LAUNCH("k_gemm_tn(edges)");
         ReduceDst rd = {};
         rd.n = 2; rd.dst[0] = G[4]; rd.dst[1] = G[5];
         rd.off[0] = 0; rd.off[1] = H * H; rd.off[2] = slab;
+        GCN_PROF_PRE("k_reduce_slabs(edges)");
         k_reduce_slabs<<<(slab + 255) / 256, 256, 0, st>>>(W.tn_e, W.S_e, slab, rd);
         GCN_CHECK_LAUNCH("k_reduce_slabs(edges)");
     }
     {
         TnProblems pr = {};
+        GCN_PROF_PRE("k_gemm_tn(nodes)");
         pr.X[0] = W.dxtmp; pr.Y[0] = x_in;   // node_feat.U
         pr.X[1] = W.dVn; pr.Y[1] = x_in;     // node_feat.V
         pr.X[2] = W.dVe; pr.Y[2] = x_in;     // edge_feat.V
@@ -223,6 +268,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
         rd.dst[0] = G[0]; rd.dst[1] = G[1]; rd.dst[2] = G[2]; rd.dst[3] = G[3]; rd.dst[4] = G[6]; rd.dst[5] = G[7];
         for (int k = 0; k < 3; ++k) { rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H; }
         rd.off[6] = 3 * slab;
+        GCN_PROF_PRE("k_reduce_slabs(nodes)");
         k_reduce_slabs<<<(3 * slab + 255) / 256, 256, 0, st>>>(W.tn_n, W.S_n, 3 * slab, rd);
         GCN_CHECK_LAUNCH("k_reduce_slabs(nodes)");
     }
@@ -348,6 +394,33 @@ HeadParams head_params(const ModelPlan& p, const float* const* P) {
 extern "C" {
 
 int gcn_abi_version(void) { return GCN_ABI_VERSION; }
+
+int gcn_prof_begin(const char* kernel_substr) {
+    if (!kernel_substr) return fail(-1, "gcn_prof_begin: null name");
+    for (auto& e : g_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    g_prof.ev.clear();
+    g_prof.pending = nullptr;
+    strncpy(g_prof.match, kernel_substr, sizeof(g_prof.match) - 1);
+    g_prof.match[sizeof(g_prof.match) - 1] = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+int gcn_prof_end(double* total_ms, int* launches) {
+    g_prof.on = false;
+    double tot = 0;
+    int n = 0;
+    for (auto& e : g_prof.ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    g_prof.ev.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return 0;
+}
 const char* gcn_last_error(void) { return g_err; }
 
 size_t gcn_layer_saved_floats(int B, int V, int C, int H) {
@@ -433,8 +506,10 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const size_t nh = d.Rn * H, eh = d.Re * H;
     float* x_act = saved + p.x_act;
     float* e_act = saved + p.e_act;
+    GCN_PROF_PRE("k_embed_edges");
     k_embed_edges<<<elem_blocks(d.Re * (H / 4)), 256, 0, st>>>(d.Re * (size_t)(H / 4), d.C, H, cap, P[2], e_act);
     GCN_CHECK_LAUNCH("k_embed_edges");
+    GCN_PROF_PRE("k_embed_nodes");
     k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act);
     GCN_CHECK_LAUNCH("k_embed_nodes");
     for (int l = 0; l < p.L; ++l) {
@@ -450,10 +525,12 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     if (m->has_labels) {
         if (hipMemsetAsync(err_counts, 0, sizeof(int) * 2 * (size_t)d.B * d.C, st) != hipSuccess) return fail(-3, "memset failed");
     }
+    GCN_PROF_PRE("k_head_fwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, e_act + (size_t)p.L * eh, cap, y_edges, edge_cw,
                                                                       y_pred, W.loss_partial, err_counts, rng, W.head_blk, st))));
     GCN_CHECK_LAUNCH("k_head_fwd");
     if (m->has_labels) {
+        GCN_PROF_PRE("k_loss_finalize");
         k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
                                                  err_flags);
         GCN_CHECK_LAUNCH("k_loss_finalize");
@@ -482,6 +559,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     const HeadParams hp = head_params(p, P);
     const int hbase = 3 + GCN_LAYER_NPARAMS * p.L;
     const int slab = H * H + H;
+    GCN_PROF_PRE("k_head_bwd");
     float* dpre_all = p.NHID == 1 ? W.lw.det : W.dpre_stash;   // [NHID][Re*H], see carve_model_bwd
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, e_act + (size_t)p.L * eh, cap, y_edges, edge_cw,
                                                                       loss_out, dloss, dy_pred, W.de, dpre_all, W.h_stash,
@@ -492,6 +570,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         ReduceDst rd = {};
         rd.n = 2; rd.dst[0] = G[hbase + 2 * p.NHID]; rd.dst[1] = G[hbase + 2 * p.NHID + 1];
         rd.off[0] = 0; rd.off[1] = p.voc * H; rd.off[2] = p.voc * H + p.voc;
+        GCN_PROF_PRE("k_reduce_slabs(head out)");
         k_reduce_slabs<<<(wcols + 255) / 256, 256, 0, st>>>(W.wpartial, W.head_blk * GCN_WAVES_PER_BLOCK, wcols, rd);
         GCN_CHECK_LAUNCH("k_reduce_slabs(head out)");
     }
@@ -501,6 +580,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             pr.X[k] = dpre_all + (size_t)k * eh;
             pr.Y[k] = k == 0 ? e_act + (size_t)p.L * eh : W.h_stash + (size_t)(k - 1) * eh;
         }
+        GCN_PROF_PRE("k_gemm_tn(head)");
         DISPATCH_MT(d.MT, (k_gemm_tn<MT><<<dim3(W.S_h, (MT + 3) / 4, p.NHID), GCN_BLOCK, 0, st>>>(d.Re, H, p.NHID, pr, W.tn_h)));
         GCN_CHECK_LAUNCH("k_gemm_tn(head)");
         ReduceDst rd = {};
@@ -510,6 +590,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H;
         }
         rd.off[2 * p.NHID] = p.NHID * slab;
+        GCN_PROF_PRE("k_reduce_slabs(head hidden)");
         k_reduce_slabs<<<(p.NHID * slab + 255) / 256, 256, 0, st>>>(W.tn_h, W.S_h, p.NHID * slab, rd);
         GCN_CHECK_LAUNCH("k_reduce_slabs(head hidden)");
     }
@@ -525,21 +606,78 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         if (rc) return rc;
     }
     // embeddings
+    GCN_PROF_PRE("k_embed_bwd_edges");
     DISPATCH_MT(d.MT, (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
     GCN_CHECK_LAUNCH("k_embed_bwd_edges");
     {
         ReduceDst rd = {};
         rd.n = 1; rd.dst[0] = G[2]; rd.off[0] = 0; rd.off[1] = H;
+        GCN_PROF_PRE("k_reduce_slabs(edge embedding)");
         k_reduce_slabs<<<(H + 255) / 256, 256, 0, st>>>(W.embpart, W.emb_blk * GCN_WAVES_PER_BLOCK, H, rd);
         GCN_CHECK_LAUNCH("k_reduce_slabs(edge embedding)");
     }
     {
         const int hh = H / 2;
         const int threads = std::max(64, std::min(256, (256 / hh) * hh >= hh ? 256 : hh));
+        GCN_PROF_PRE("k_embed_bwd_nodes");
         k_embed_bwd_nodes<<<m->n_emb + 1, threads, threads * sizeof(double), st>>>(d.B, d.V, d.C, H, m->n_emb, x_nodes, demand,
                                                                                 W.dx, G[0], G[1]);
         GCN_CHECK_LAUNCH("k_embed_bwd_nodes");
     }
+    return 0;
+}
+
+
+// ---- beam search ---------------------------------------------------------------------------------
+size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
+    (void)C; (void)K;
+    if (B <= 0 || V <= 0) return 0;
+    return align_up((size_t)B * V * V * sizeof(float));
+}
+
+int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
+                    const float* cap, const long long* comm, const int* perms, int n_perms, const int* perm_start,
+                    const unsigned char* run_mask, int* paths, int* path_len, int* feasible, int* attempts, void* ws,
+                    size_t ws_bytes, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || K <= 0) return fail(-1, "gcn_beam_search: non-positive dimension B=%d V=%d C=%d K=%d", B, V, C, K);
+    if (V > 65535) return fail(-1, "gcn_beam_search: V=%d exceeds 65535", V);
+    if (algorithm < 0 || algorithm > 3) return fail(-1, "gcn_beam_search: unknown algorithm id %d", algorithm);
+    if (max_iter < 1) return fail(-1, "gcn_beam_search: max_iter %d < 1", max_iter);
+    if (!y || !cap || !comm || !paths || !path_len || !feasible || !attempts) return fail(-1, "gcn_beam_search: null pointer argument");
+    const bool needs_perms = algorithm == BEAM_ALGO_STANDARD || algorithm == BEAM_ALGO_GREEDY;
+    if (needs_perms && (!perms || !perm_start || n_perms < 1)) return fail(-1, "gcn_beam_search: this algorithm needs permutations");
+    const bool strict = mode_strict && algorithm != BEAM_ALGO_UNCONSTRAINED;
+    int cap_in_lds = strict && ((size_t)V * V * sizeof(float) <= 32768) ? 1 : 0;
+    if (strict && !cap_in_lds) {
+        if (!ws || ws_bytes < gcn_beam_ws_bytes(B, V, C, K)) return fail(-2, "gcn_beam_search: workspace too small");
+    }
+    const size_t lds = beam_lds_bytes(V, K, cap_in_lds);
+    if (lds > 160 * 1024) return fail(-1, "gcn_beam_search: beam state of %zu bytes exceeds the 160 KiB LDS (V=%d, K=%d)", lds, V, K);
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(-3, "gcn_beam_search: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    }
+    const int jobs = algorithm == BEAM_ALGO_UNCONSTRAINED ? B * C : B;
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_beam_search");
+    k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, strict ? 1 : 0, max_iter, y, cap, comm, perms,
+                                                          n_perms, perm_start, run_mask, (float*)ws, cap_in_lds, paths, path_len,
+                                                          feasible, attempts);
+    GCN_CHECK_LAUNCH("k_beam_search");
+    return 0;
+}
+
+int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || !in || !y) return fail(-1, "gcn_beam_scores: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (five_d) {
+        const size_t rows = (size_t)B * V * V * C;
+        k_beam_scores_2class<<<elem_blocks(rows), 256, 0, st>>>(rows, in, y);
+    } else {
+        k_beam_scores_over_j<<<elem_blocks((size_t)B * V * C), 256, 0, st>>>(B, V, C, in, y);
+    GCN_PROF_PRE("k_beam_scores");
+    }
+    GCN_CHECK_LAUNCH("k_beam_scores");
     return 0;
 }
 

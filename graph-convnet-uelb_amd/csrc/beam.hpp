@@ -1,0 +1,297 @@
+// Capacity-aware beam search on the GPU (gfx950): one wavefront per graph (or per (graph, commodity)
+// for the unconstrained algorithm), beams and candidates resident in LDS.
+//
+// Restates src/gcn/algorithms/beamsearch_uelb.py of the reference so that the decoded paths are
+// bit-identical for the same log-probabilities y:
+//   * scores are fp32 and are added left to right along the path (:158-159);
+//   * each iteration keeps the first K entries of the queue sorted by score descending with
+//     insertion order breaking ties (Python's stable sorted(..., reverse=True), :144) -- here K rounds
+//     of a wavefront arg-max over (score, candidate index);
+//   * queue entries that sit on the target occupy beam slots and become result candidates (:148-150);
+//     the result is the earliest found path with the strictly highest score (:173);
+//   * a neighbour is skipped if it is already on the path (:153), if the edge has zero capacity at the
+//     start of this commodity (:155) or, except for "unconstrained", if demand > capacity (:161; paths
+//     are simple, so the per-path remaining capacity of edge (cur, n) equals that entry capacity);
+//   * strict mode subtracts the demand along the chosen path before the next commodity (:123-124);
+//   * standard / greedy process commodities in the order of a permutation drawn per attempt (:99, :299),
+//     retry up to max_iter times and fall back to [0..9] per commodity (:131-133, :179-181).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BEAM_ALGO_STANDARD 0
+#define BEAM_ALGO_DETERMINISTIC 1
+#define BEAM_ALGO_GREEDY 2
+#define BEAM_ALGO_UNCONSTRAINED 3
+
+struct BeamCand {
+    float score;
+    int idx;      // candidate index k*V + n, or -1 if none
+};
+
+__device__ __forceinline__ bool beam_better(const BeamCand& a, const BeamCand& b) {
+    if (a.idx < 0) return false;
+    if (b.idx < 0) return true;
+    if (a.score > b.score) return true;
+    if (a.score < b.score) return false;
+    return a.idx < b.idx;
+}
+
+__device__ __forceinline__ BeamCand beam_wave_best(BeamCand c) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        BeamCand o;
+        o.score = __shfl_xor(c.score, off, 64);
+        o.idx = __shfl_xor(c.idx, off, 64);
+        if (beam_better(o, c)) c = o;
+    }
+    return c;
+}
+
+// LDS carve (bytes), all regions 16-byte aligned:
+//   cand_score float[K*V] | cand_ok u8[K*V] | path u16[2][K][V] | visited u32[2][K][VW] |
+//   beam_node int[2][K] | beam_score float[2][K] | best_path u16[V] | wcap float[V*V] (optional)
+struct BeamLds {
+    float* cand_score;
+    unsigned char* cand_ok;
+    unsigned short* path;
+    unsigned int* visited;
+    int* beam_node;
+    float* beam_score;
+    unsigned short* best_path;
+    float* wcap;
+};
+
+__host__ __device__ inline size_t beam_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds) {
+    const int VW = (V + 31) / 32;
+    size_t s = 0;
+    s += beam_align16((size_t)K * V * 4);
+    s += beam_align16((size_t)K * V);
+    s += beam_align16((size_t)2 * K * V * 2);
+    s += beam_align16((size_t)2 * K * VW * 4);
+    s += beam_align16((size_t)2 * K * 4);
+    s += beam_align16((size_t)2 * K * 4);
+    s += beam_align16((size_t)V * 2);
+    if (cap_in_lds) s += beam_align16((size_t)V * V * 4);
+    return s;
+}
+
+__device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds) {
+    const int VW = (V + 31) / 32;
+    BeamLds l;
+    l.cand_score = (float*)base; base += beam_align16((size_t)K * V * 4);
+    l.cand_ok = (unsigned char*)base; base += beam_align16((size_t)K * V);
+    l.path = (unsigned short*)base; base += beam_align16((size_t)2 * K * V * 2);
+    l.visited = (unsigned int*)base; base += beam_align16((size_t)2 * K * VW * 4);
+    l.beam_node = (int*)base; base += beam_align16((size_t)2 * K * 4);
+    l.beam_score = (float*)base; base += beam_align16((size_t)2 * K * 4);
+    l.best_path = (unsigned short*)base; base += beam_align16((size_t)V * 2);
+    l.wcap = cap_in_lds ? (float*)base : nullptr;
+    return l;
+}
+
+// One commodity.  capm: [V][V] capacities valid at the start of this commodity (LDS or global).
+// yb: y + b*V*V*C + c, element (i, j) at yb[(i*V + j)*C].  Returns the length of the best path
+// (written to L.best_path), 0 if none.  All 64 lanes must call it.
+__device__ inline int beam_commodity(const BeamLds& L, const float* capm, const float* __restrict__ yb, int V, int C,
+                                     int K, int src, int dst, float demand, int check_demand) {
+    const int lane = threadIdx.x;
+    const int VW = (V + 31) / 32;
+    int gen = 0, nb = 1, len = 1;
+    bool have_best = false;
+    float best_score = 0.f;
+    int best_len = 0;
+    if (lane == 0) {
+        L.beam_node[0] = src;
+        L.beam_score[0] = 0.f;
+        L.path[0] = (unsigned short)src;
+    }
+    for (int w = lane; w < VW; w += 64) L.visited[w] = (w == (src >> 5)) ? (1u << (src & 31)) : 0u;
+    __syncthreads();
+    while (nb > 0) {
+        const unsigned short* gpath = L.path + (size_t)gen * K * V;
+        const unsigned int* gvis = L.visited + (size_t)gen * K * VW;
+        const int* gnode = L.beam_node + gen * K;
+        const float* gscore = L.beam_score + gen * K;
+        // beams on the target become result candidates, in rank order, strict > keeps the earliest
+        for (int r = 0; r < nb; ++r) {
+            if (gnode[r] == dst) {
+                const float s = gscore[r];
+                if (!have_best || s > best_score) {
+                    have_best = true; best_score = s; best_len = len;
+                    for (int t = lane; t < len; t += 64) L.best_path[t] = gpath[(size_t)r * V + t];
+                }
+            }
+        }
+        // expansion: candidate (k, n) in beam-rank order, n ascending
+        const int ncand = nb * V;
+        int any = 0;
+        for (int idx = lane; idx < ncand; idx += 64) {
+            const int k = idx / V, n = idx - k * V;
+            const int node = gnode[k];
+            bool ok = node != dst;
+            ok = ok && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
+            float sc = 0.f;
+            if (ok) {
+                const float cv = capm[node * V + n];
+                ok = (cv != 0.f) && (!check_demand || demand <= cv);
+                if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
+            }
+            L.cand_score[idx] = sc;
+            L.cand_ok[idx] = ok ? 1 : 0;
+            any |= ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!__any(any)) break;
+        // stable top-K: K rounds of arg-max over (score desc, idx asc)
+        const int ngen = gen ^ 1;
+        unsigned short* npath = L.path + (size_t)ngen * K * V;
+        unsigned int* nvis = L.visited + (size_t)ngen * K * VW;
+        int nnb = 0;
+        for (int r = 0; r < K; ++r) {
+            BeamCand c;
+            c.idx = -1; c.score = 0.f;
+            for (int idx = lane; idx < ncand; idx += 64) {
+                if (L.cand_ok[idx]) {
+                    BeamCand o;
+                    o.idx = idx; o.score = L.cand_score[idx];
+                    if (beam_better(o, c)) c = o;
+                }
+            }
+            c = beam_wave_best(c);
+            if (c.idx < 0) break;
+            const int k = c.idx / V, n = c.idx - k * V;
+            if (lane == 0) {
+                L.cand_ok[c.idx] = 0;
+                L.beam_node[ngen * K + r] = n;
+                L.beam_score[ngen * K + r] = c.score;
+                npath[(size_t)r * V + len] = (unsigned short)n;
+            }
+            for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
+            for (int w = lane; w < VW; w += 64)
+                nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+            nnb = r + 1;
+            __syncthreads();
+        }
+        gen = ngen; nb = nnb; len += 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    return have_best ? best_len : 0;
+}
+
+// jobs: graphs (algorithms 0..2) or graph x commodity (algorithm 3).  blockDim = 64.
+// perms: [n_perms][C] int32; perm_start[b]: index of graph b's first permutation.
+// run_mask (nullable): graphs with run_mask[b] == 0 are skipped (outputs untouched).
+// capws: [B][V][V] floats of global scratch, used as the working capacity in strict mode when the
+// matrix does not fit LDS.  paths: [B][C][PL] int32 padded with -1, PL = max(V, 10).
+__global__ __launch_bounds__(64) void k_beam_search(
+    int B, int V, int C, int K, int algo, int strict, int max_iter, const float* __restrict__ y,
+    const float* __restrict__ cap, const long long* __restrict__ comm, const int* __restrict__ perms, int n_perms,
+    const int* __restrict__ perm_start, const unsigned char* __restrict__ run_mask, float* __restrict__ capws,
+    int cap_in_lds, int* __restrict__ paths, int* __restrict__ path_len, int* __restrict__ feasible,
+    int* __restrict__ attempts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int PL = V > 10 ? V : 10;
+    const BeamLds L = beam_carve(smem, V, K, cap_in_lds && strict && algo != BEAM_ALGO_UNCONSTRAINED);
+    if (algo == BEAM_ALGO_UNCONSTRAINED) {
+        const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+        if (run_mask && !run_mask[b]) return;
+        const long long* cm = comm + ((size_t)b * C + c) * 3;
+        const int len = beam_commodity(L, cap + (size_t)b * V * V, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0],
+                                       (int)cm[1], 0.f, 0);
+        int* pb = paths + ((size_t)b * C + c) * PL;
+        for (int t = lane; t < PL; t += 64) pb[t] = t < len ? (int)L.best_path[t] : -1;
+        if (lane == 0) {
+            path_len[(size_t)b * C + c] = len;
+            if (c == 0) { feasible[b] = 1; attempts[b] = 0; }
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    if (run_mask && !run_mask[b]) return;
+    if (algo == BEAM_ALGO_GREEDY) K = 1;
+    const float* cap_b = cap + (size_t)b * V * V;
+    float* wcap = strict ? (L.wcap ? L.wcap : capws + (size_t)b * V * V) : nullptr;
+    const float* yb = y + (size_t)b * V * V * C;
+    const long long* cm = comm + (size_t)b * C * 3;
+    int* pb = paths + (size_t)b * C * PL;
+    int* plb = path_len + (size_t)b * C;
+    int used = 0, ok = 0;
+    for (int count = 0; count < max_iter; ++count) {
+        const int* perm = nullptr;
+        if (algo != BEAM_ALGO_DETERMINISTIC) {
+            const int pi = perm_start[b] + count;
+            if (pi >= n_perms) break;          // host supplies max_iter permutations per graph; defensive
+            perm = perms + (size_t)pi * C;
+        }
+        ++used;
+        if (strict) {
+            for (int t = lane; t < V * V; t += 64) wcap[t] = cap_b[t];
+        }
+        __syncthreads();
+        ok = 1;
+        for (int pos = 0; pos < C; ++pos) {
+            const int c = perm ? perm[pos] : pos;
+            const int s = (int)cm[c * 3], d = (int)cm[c * 3 + 1];
+            const float demand = (float)cm[c * 3 + 2];
+            const int len = beam_commodity(L, strict ? wcap : cap_b, yb + c, V, C, K, s, d, demand, 1);
+            if (len == 0) { ok = 0; break; }
+            for (int t = lane; t < PL; t += 64) pb[(size_t)c * PL + t] = t < len ? (int)L.best_path[t] : -1;
+            if (lane == 0) plb[c] = len;
+            if (strict) {
+                for (int t = lane; t + 1 < len; t += 64) {
+                    const int u = L.best_path[t], v = L.best_path[t + 1];
+                    wcap[u * V + v] -= demand;      // a simple path uses each directed edge once
+                }
+            }
+            __syncthreads();
+        }
+        if (ok) break;
+        if (algo == BEAM_ALGO_DETERMINISTIC) { used = max_iter; break; }   // identical retries, identical result
+    }
+    if (!ok) {
+        for (int t = lane; t < C * PL; t += 64) {
+            const int col = t % PL;
+            pb[t] = col < 10 ? col : -1;
+        }
+        for (int c = lane; c < C; c += 64) plb[c] = 10;
+    }
+    if (lane == 0) { feasible[b] = ok; attempts[b] = used; }
+}
+
+// y from the network output, BeamSearchAlgorithm.__init__ (:14-21).
+// five_d != 0: logits [rows][2] -> y[row] = log_softmax(.)[1]; thread per row.
+__global__ void k_beam_scores_2class(size_t rows, const float* __restrict__ logits, float* __restrict__ y) {
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
+        const float l0 = logits[r * 2], l1 = logits[r * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float lse = logf(expf(l0 - mx) + expf(l1 - mx));
+        float v = (l1 - mx) - lse;
+        if (v == 0.f) v = -1e-20f;
+        y[r] = v;
+    }
+}
+// scores [B][V_i][V_j][C] -> log_softmax over j; thread per (b, i, c).
+__global__ void k_beam_scores_over_j(int B, int V, int C, const float* __restrict__ s, float* __restrict__ y) {
+    const size_t n = (size_t)B * V * C;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t bi = t / C;
+        const int c = (int)(t - bi * C);
+        const float* p = s + bi * V * C + c;
+        float mx = -INFINITY;
+        for (int j = 0; j < V; ++j) mx = fmaxf(mx, p[(size_t)j * C]);
+        float sum = 0.f;
+        for (int j = 0; j < V; ++j) sum += expf(p[(size_t)j * C] - mx);
+        const float lse = logf(sum);
+        float* o = y + bi * V * C + c;
+        for (int j = 0; j < V; ++j) {
+            float v = (p[(size_t)j * C] - mx) - lse;
+            if (v == 0.f) v = -1e-20f;
+            o[(size_t)j * C] = v;
+        }
+    }
+}

@@ -39,6 +39,10 @@ _lib = None
 def _declare(lib):
     lib.gcn_abi_version.restype = c_int
     lib.gcn_last_error.restype = c_char_p
+    lib.gcn_prof_begin.restype = c_int
+    lib.gcn_prof_begin.argtypes = [c_char_p]
+    lib.gcn_prof_end.restype = c_int
+    lib.gcn_prof_end.argtypes = [POINTER(ctypes.c_double), POINTER(c_int)]
     for name in ("gcn_layer_saved_floats", "gcn_layer_ws_bytes"):
         fn = getattr(lib, name)
         fn.restype = c_size_t
@@ -70,8 +74,9 @@ def _declare(lib):
         lib.gcn_edge_error.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     if hasattr(lib, "gcn_beam_search"):
         lib.gcn_beam_search.restype = c_int
-        lib.gcn_beam_search.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        lib.gcn_beam_search.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]
         lib.gcn_beam_ws_bytes.restype = c_size_t
         lib.gcn_beam_ws_bytes.argtypes = [c_int, c_int, c_int, c_int]
     if hasattr(lib, "gcn_beam_scores"):

@@ -37,6 +37,13 @@ extern "C" {
 int gcn_abi_version(void);
 const char* gcn_last_error(void);
 
+/* Measurement aid, no counterpart in the reference: after gcn_prof_begin(substr) every launch whose
+ * kernel name contains substr is bracketed by two HIP events on the stream it is launched on;
+ * gcn_prof_end() waits for them and returns their summed elapsed time and count.  Host-side only,
+ * not for use while a stream is being captured into a graph. */
+int gcn_prof_begin(const char* kernel_substr);
+int gcn_prof_end(double* total_ms, int* launches);
+
 /* ------------------------------------------------------------------------------------------------
  * One residual gated graph-conv layer.
  * Replaces ResidualGatedGCNLayer.forward (src/gcn/models/gcn_layers.py:108-129), i.e.
@@ -107,6 +114,32 @@ int gcn_model_bwd(const gcn_model_desc* d, const float* cap, const float* demand
                   const unsigned long long* rng, const float* saved, const float* loss_out,
                   const float* dloss, const float* dy_pred, float* const* grads,
                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Capacity-aware beam search, batched on the GPU.
+ * Replaces BeamSearchAlgorithm.search / _search_single_batch / _beam_search_for_commodity of the
+ * four algorithms in src/gcn/algorithms/beamsearch_uelb.py (:37-55, :89-177, :187-274, :289-377,
+ * :387-457) and the score preparation of BeamSearchAlgorithm.__init__ (:14-21).
+ *
+ * algorithm: 0 standard, 1 deterministic, 2 greedy (beam size forced to 1), 3 unconstrained.
+ * y [B,V,V,C] fp32 log-probabilities, cap [B,V,V] fp32, comm [B,C,3] int64 (src, dst, demand).
+ * perms [n_perms,C] int32: the permutations torch.randperm(C) would return, in draw order;
+ * perm_start[b] int32: index of graph b's first permutation (graph b uses perm_start[b] + attempt).
+ * run_mask uint8 [B] (NULL = all): graphs with 0 are skipped and their outputs left untouched.
+ * Outputs: paths int32 [B,C,PL] padded with -1, PL = max(V, 10); path_len int32 [B,C];
+ * feasible int32 [B]; attempts int32 [B] (permutations consumed by standard / greedy).
+ * ws: gcn_beam_ws_bytes() bytes, used only in strict mode when V*V*4 > 32 KiB.
+ * ---------------------------------------------------------------------------------------------- */
+size_t gcn_beam_ws_bytes(int B, int V, int C, int K);
+int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
+                    const float* cap, const long long* comm, const int* perms, int n_perms, const int* perm_start,
+                    const unsigned char* run_mask, int* paths, int* path_len, int* feasible, int* attempts, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* five_d != 0: in = logits [B,V,V,C,2], y = log_softmax(in, dim 4)[..., 1];
+ * five_d == 0: in = scores [B,V,V,C],   y = log_softmax(in, dim 2) (over the next node j).
+ * Exact zeros become -1e-20 (beamsearch_uelb.py:21). */
+int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, void* stream);
 
 #ifdef __cplusplus
 }

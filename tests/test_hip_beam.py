@@ -1,0 +1,125 @@
+"""GPU beam search against the reference's golden paths and the C oracle (bit-exact)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden
+from oracle import beam_oracle_c
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    return torch.device("cuda:0")
+
+
+def _make(algo, y_or_logits, cap, comm, K, strict, max_iter, dev, use_y=True):
+    from src.gcn.algorithms.beamsearch_uelb import BeamSearchFactory
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B, V = cap.shape[0], cap.shape[1]
+    C = comm.shape[1]
+    dummy = torch.zeros((B, V, V, C), device=dev)
+    a = BeamSearchFactory.create_algorithm(algo, y_pred_edges=dummy if use_y else t(y_or_logits), beam_size=K,
+                                           batch_size=B, edges_capacity=t(cap), commodities=t(comm),
+                                           dtypeFloat=torch.float32, dtypeLong=torch.long, mode_strict=strict,
+                                           max_iter=max_iter)
+    if use_y:
+        a.y = t(y_or_logits)          # parity is defined on identical log-probabilities
+    return a
+
+
+def _unpack(paths, plen):
+    paths, plen = np.asarray(paths), np.asarray(plen)
+    return [[[int(v) for v in paths[b, c, :plen[b, c]]] for c in range(paths.shape[1])] for b in range(paths.shape[0])]
+
+
+@pytest.mark.parametrize("path", golden_files("beam"), ids=os.path.basename)
+def test_beam_matches_reference_golden(path, monkeypatch):
+    dev = _dev()
+    g = load_golden(path)
+    algo, K = str(g["cfg_algorithm"]), int(g["cfg_K"])
+    strict, max_iter = bool(g["cfg_strict"]), int(g["cfg_max_iter"])
+    a = _make(algo, g["in_y"], g["in_cap"], g["in_comm"], K, strict, max_iter, dev)
+    # feed the permutations the reference drew, in order; anything beyond them is filler that an exact
+    # implementation never consumes
+    golden = [torch.from_numpy(p.astype(np.int64)) for p in g["in_perms"]]
+    calls = {"n": 0}
+    C = int(g["cfg_C"])
+
+    def fake_randperm(n, *args, **kw):
+        i = calls["n"]
+        calls["n"] += 1
+        return golden[i].clone() if i < len(golden) else torch.arange(n - 1, -1, -1)
+
+    monkeypatch.setattr(torch, "randperm", fake_randperm)
+    paths, is_feasible = a.search()
+    want = _unpack(g["out_paths"], g["out_path_len"])
+    assert paths == want
+    assert [int(v) for v in a.feasible_per_graph.cpu()] == [int(v) for v in g["out_feasible"]]
+    assert is_feasible == bool(g["out_feasible"][-1])
+    if algo in ("standard", "greedy"):
+        assert int(a.attempts.sum()) == len(golden)
+        # pre-draw of B*max_iter plus exactly the reference's number of draws afterwards
+        assert calls["n"] == int(g["cfg_B"]) * max_iter + len(golden)
+
+
+def test_seeded_standard_search_consumes_generator_like_reference():
+    """With torch.manual_seed the class draws the same permutations as the reference did and leaves the
+    global generator in the state the reference would leave it in."""
+    dev = _dev()
+    g = load_golden([p for p in golden_files("beam") if p.endswith("beam_std_tight.npz")][0])
+    a = _make("standard", g["in_y"], g["in_cap"], g["in_comm"], int(g["cfg_K"]), True, int(g["cfg_max_iter"]), dev)
+    torch.manual_seed(14)             # the seed gen_golden.py used for this case
+    paths, _ = a.search()
+    after = torch.rand(1).item()
+    assert paths == _unpack(g["out_paths"], g["out_path_len"])
+    torch.manual_seed(14)
+    for _ in range(len(g["in_perms"])):
+        torch.randperm(int(g["cfg_C"]))
+    assert torch.rand(1).item() == after
+
+
+def test_scores_from_logits_close_to_torch():
+    dev = _dev()
+    for name in ("beam_det_strict.npz", "beam_scores4d.npz"):
+        g = load_golden([p for p in golden_files("beam") if p.endswith(name)][0])
+        a = _make("deterministic", g["in_logits"], g["in_cap"], g["in_comm"], 2, True, 5, dev, use_y=False)
+        got = a.y.cpu().numpy()
+        assert got.shape == g["in_y"].shape
+        assert np.abs(got - g["in_y"]).max() <= 1e-5 * max(1.0, np.abs(g["in_y"]).max())
+        assert not (got == 0).any()
+
+
+@pytest.mark.parametrize("algo,strict,V,C,K,B", [("deterministic", True, 14, 20, 10, 40), ("standard", True, 14, 10, 10, 60),
+                                                  ("unconstrained", False, 14, 20, 10, 20), ("greedy", True, 30, 6, 5, 16),
+                                                  ("deterministic", False, 40, 5, 10, 20), ("deterministic", True, 100, 4, 10, 4),
+                                                  ("standard", True, 6, 4, 3, 33), ("deterministic", True, 5, 3, 50, 3)])
+def test_beam_matches_c_oracle_at_benchmark_sizes(algo, strict, V, C, K, B):
+    """Random instances at and beyond the configs' sizes (V = 100 exercises the capacity matrix in
+    global scratch instead of LDS; K = 50 > candidates exercises short queues)."""
+    from src.common.synthetic import make_batch
+    dev = _dev()
+    rng = np.random.default_rng(V * 100 + C)
+    b = make_batch(B, V, C, "nsfnet" if V == 14 else "random", 300 if algo == "standard" else 1000, 5000, 5, 500, seed=V + C)
+    y = np.log(rng.random((B, V, V, C)).astype(np.float32) * 0.98 + 0.01).astype(np.float32)
+    y[rng.random(y.shape) < 0.2] = np.float32(-0.5)      # ties
+    max_iter = 5
+    perms = np.stack([rng.permutation(C) for _ in range(B * max_iter)]).astype(np.int32)
+    rp, rl, rf, ratt, used = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, algo, strict, max_iter, perms)
+    a = _make(algo, y, b["edges_capacity"], b["commodities"], K, strict, max_iter, dev)
+    it = iter([torch.from_numpy(p.astype(np.int64)) for p in perms])
+    orig = torch.randperm
+    torch.randperm = lambda n, *args, **kw: next(it, torch.arange(n))
+    try:
+        a.search()
+    finally:
+        torch.randperm = orig
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+    if algo in ("standard", "greedy"):
+        assert int(a.attempts.sum()) == used
