@@ -135,7 +135,7 @@ LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     w.nblk = wave_blocks(d.Rn);
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
-    w.partial = b.f((size_t)w.nblk * GCN_WAVES_PER_BLOCK * 4 * d.H);
+    w.partial = b.f((size_t)w.nblk * 4 * d.H);
     return w;
 }
 
@@ -144,25 +144,24 @@ int tn_slices(size_t rows) {
     return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
 }
 
+constexpr int kMaxPartBlocks = 512;    // wave_blocks() cap: rows of the BatchNorm-backward partial buffers
+
 struct LayerBwdWs {
-    float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *qv, *rowpart, *colVe, *colVn, *dVe, *dVn;
+    float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
     float *tn_e, *tn_n;
-    int nblk_e, nblk_x, S_e, S_n;
+    int S_e, S_n;
 };
 LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
     LayerBwdWs w;
     const size_t nh = d.Rn * d.H;
-    w.nblk_e = wave_blocks((d.Re + 15) / 16);
-    w.nblk_x = wave_blocks((d.Rn + 15) / 16);
     w.S_e = tn_slices(d.Re);
     w.S_n = tn_slices(d.Rn);
     w.det = b.f(d.Re * d.H);
-    w.bpart_e = b.f((size_t)w.nblk_e * GCN_WAVES_PER_BLOCK * 2 * d.H);
-    w.bpart_x = b.f((size_t)w.nblk_x * GCN_WAVES_PER_BLOCK * 2 * d.H);
+    w.bpart_e = b.f((size_t)kMaxPartBlocks * 2 * d.H);
+    w.bpart_x = b.f((size_t)kMaxPartBlocks * 2 * d.H);
     w.bstats_e = b.f(2 * d.H);
     w.bstats_x = b.f(2 * d.H);
     w.dxtmp = b.f(nh);
-    w.qv = b.f(nh);
     w.rowpart = b.f((size_t)d.njt * nh);
     w.colVe = b.f((size_t)d.nit * nh);
     w.colVn = b.f((size_t)d.nit * nh);
@@ -175,72 +174,147 @@ LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------
+// What precedes a layer's kernels: nothing (inputs given), the previous layer (its BatchNorm apply is fused
+// into this layer's loads) or the embedding.
+struct PrevLayer {
+    int kind;                       // 0 none, 1 previous layer, 2 embedding (edges only; nodes are given)
+    const float *e_tmp, *e_in, *x_tmp, *x_in, *stats;
+    const float *gamma_x, *beta_x, *gamma_e, *beta_e;
+    int sid;                        // dropout stream base of that layer
+    const float *cap, *we;
+};
+
+EdgeSrc make_edge_src(const PrevLayer& pv, const float* e_in, float* e_out, int H, float p, int training) {
+    EdgeSrc s = {};
+    if (pv.kind == 1) {
+        s.mode = 1; s.prev_tmp = pv.e_tmp; s.prev_in = pv.e_in; s.e_out = e_out;
+        s.pmean = pv.stats; s.prstd = pv.stats + H; s.pgamma = pv.gamma_e; s.pbeta = pv.beta_e;
+        s.drop_sid = 2 * pv.sid; s.drop_p = p; s.drop_on = training;
+    } else if (pv.kind == 2) {
+        s.mode = 2; s.cap = pv.cap; s.we = pv.we; s.e_out = e_out;
+    } else {
+        s.mode = 0; s.e_in = e_in;
+    }
+    return s;
+}
+
+// forward of one layer up to the BatchNorm statistics (the apply is left to the consumer)
+template <int MT>
+int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned long long* rng, const PrevLayer& pv,
+                   const float* x_in, float* x_in_out, const float* e_in, float* e_in_out, const float* const* P,
+                   const LayerSaved& S, const LayerFwdWs& W, hipStream_t st) {
+    const int H = d.H;
+    {
+        NodeFwdArgs a = {};
+        a.rows = (int)d.Rn; a.H = H; a.apply = pv.kind == 1;
+        a.x_in = x_in; a.prev_tmp = pv.x_tmp; a.prev_in = pv.x_in; a.x_out = x_in_out;
+        if (a.apply) { a.pmean = pv.stats + 2 * H; a.prstd = pv.stats + 3 * H; a.pgamma = pv.gamma_x; a.pbeta = pv.beta_x; }
+        a.drop_sid = 2 * pv.sid + 1; a.drop_p = p; a.drop_on = training;
+        a.W[0] = P[0]; a.bias[0] = P[1]; a.y[0] = W.Ux;
+        a.W[1] = P[2]; a.bias[1] = P[3]; a.y[1] = S.Vn;
+        a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
+        a.rng = rng;
+        GCN_PROF_PRE("k_node_fwd2");
+        k_node_fwd2<MT><<<dim3(wave_blocks((d.Rn + 15) / 16), 3, 1), GCN_BLOCK, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_node_fwd2");
+    }
+    {
+        EdgeFwdArgs a = {};
+        a.B = d.B; a.V = d.V; a.C = d.C; a.H = H; a.mean_agg = agg;
+        a.src = make_edge_src(pv, e_in, e_in_out, H, p, training);
+        a.WU = P[4]; a.bU = P[5]; a.Ve = W.Ve; a.Vn = S.Vn; a.Ux = W.Ux;
+        a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
+        GCN_PROF_PRE("k_edge_fwd2");
+        k_edge_fwd2<MT><<<W.nblk, GCN_BLOCK, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_edge_fwd2");
+    }
+    GCN_PROF_PRE("k_bn_stats_finalize");
+    k_bn_stats_finalize<<<2 * (H / 4), GCN_BLOCK, 0, st>>>(W.partial, W.nblk, H, (double)d.Re, (double)d.Rn, S.stats);
+    GCN_CHECK_LAUNCH("k_bn_stats_finalize");
+    return 0;
+}
+
+// standalone layer: plain inputs, explicit apply kernels for both outputs
 template <int MT>
 int layer_fwd_t(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
                 const float* x_in, const float* e_in, const float* const* P, float* x_out, float* e_out,
                 const LayerSaved& S, const LayerFwdWs& W, hipStream_t st) {
     const int H = d.H;
-    GCN_PROF_PRE("k_node_gemm3");
-    k_node_gemm3<MT><<<wave_blocks((d.Rn + 15) / 16), GCN_BLOCK, 0, st>>>(
-        (int)d.Rn, H, x_in, P[0], P[1], W.Ux, P[2], P[3], S.Vn, P[6], P[7], W.Ve);
-    GCN_CHECK_LAUNCH("k_node_gemm3");
-    GCN_PROF_PRE("k_edge_fwd");
-    k_edge_fwd<MT><<<W.nblk, GCN_BLOCK, 0, st>>>(d.B, d.V, d.C, H, agg, e_in, P[4], P[5], W.Ve, S.Vn, W.Ux,
-                                                 S.e_tmp, S.x_tmp, S.A, S.D, W.partial);
-    GCN_CHECK_LAUNCH("k_edge_fwd");
-    GCN_PROF_PRE("k_bn_stats_finalize");
-    k_bn_stats_finalize<<<2 * (H / 4), GCN_BLOCK, 0, st>>>(W.partial, W.nblk * GCN_WAVES_PER_BLOCK, H, (double)d.Re,
-                                                           (double)d.Rn, S.stats);
-    GCN_CHECK_LAUNCH("k_bn_stats_finalize");
+    PrevLayer none = {};
+    if (int rc = layer_fwd_core<MT>(d, agg, p, training, rng, none, x_in, nullptr, e_in, nullptr, P, S, W, st)) return rc;
     GCN_PROF_PRE("k_bn_apply(edges)");
     k_bn_apply<<<elem_blocks(d.Re * (H / 4)), 256, 0, st>>>(d.Re, H, S.e_tmp, e_in, S.stats, S.stats + H, P[10], P[11],
                                                             e_out, rng, 2 * sid, p, training);
     GCN_CHECK_LAUNCH("k_bn_apply(edges)");
-    if (x_out != nullptr) {
-        GCN_PROF_PRE("k_bn_apply(nodes)");
-        k_bn_apply<<<elem_blocks(d.Rn * (H / 4)), 256, 0, st>>>(d.Rn, H, S.x_tmp, x_in, S.stats + 2 * H, S.stats + 3 * H,
-                                                                P[8], P[9], x_out, rng, 2 * sid + 1, p, training);
-        GCN_CHECK_LAUNCH("k_bn_apply(nodes)");
-    }
+    GCN_PROF_PRE("k_bn_apply(nodes)");
+    k_bn_apply<<<elem_blocks(d.Rn * (H / 4)), 256, 0, st>>>(d.Rn, H, S.x_tmp, x_in, S.stats + 2 * H, S.stats + 3 * H,
+                                                            P[8], P[9], x_out, rng, 2 * sid + 1, p, training);
+    GCN_CHECK_LAUNCH("k_bn_apply(nodes)");
     return 0;
 }
 
+// BatchNorm-backward statistics of the layer below (fused into this layer's backward kernels)
+struct NextLayer {
+    bool on;
+    const float *e_tmp, *x_tmp, *stats, *gamma_x, *beta_x, *gamma_e, *beta_e;
+    int sid;
+};
+
+// Backward of one layer.  On entry bpart_e / bpart_x hold npart_e / npart_x rows of this layer's
+// BatchNorm-backward partial sums; on return they hold those of the layer below if nx.on.
+// wT: transposed node_feat.U, node_feat.V, edge_feat.U, edge_feat.V weights of this layer.
 template <int MT>
-int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
-                const float* x_in, const float* e_in, const float* const* P, const LayerSaved& S, float* dx,
-                float* de, float* const* G, const LayerBwdWs& W, hipStream_t st) {
+int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
+                   const float* x_in, const float* e_in, const float* const* P, const float* const* wT, const LayerSaved& S,
+                   float* dx, float* de, float* const* G, const LayerBwdWs& W, int& npart_e, int& npart_x,
+                   const NextLayer& nx, hipStream_t st) {
     const int H = d.H;
-    GCN_PROF_PRE("k_bn_bwd_stats(edges)");
-    k_bn_bwd_stats<MT><<<W.nblk_e, GCN_BLOCK, 0, st>>>(d.Re, H, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11],
-                                                       W.bpart_e, rng, 2 * sid, p, training);
-    GCN_CHECK_LAUNCH("k_bn_bwd_stats(edges)");
-    GCN_PROF_PRE("k_bn_bwd_stats(nodes)");
-    k_bn_bwd_stats<MT><<<W.nblk_x, GCN_BLOCK, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9],
-                                                       W.bpart_x, rng, 2 * sid + 1, p, training);
-    GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
-    GCN_PROF_PRE("k_bn_bwd_finalize(edges)");
-    k_bn_bwd_finalize<<<H / 4, GCN_BLOCK, 0, st>>>(W.bpart_e, W.nblk_e * GCN_WAVES_PER_BLOCK, H, (double)d.Re, W.bstats_e,
-                                                   G[10], G[11]);
-    GCN_CHECK_LAUNCH("k_bn_bwd_finalize(edges)");
-    GCN_PROF_PRE("k_bn_bwd_finalize(nodes)");
-    k_bn_bwd_finalize<<<H / 4, GCN_BLOCK, 0, st>>>(W.bpart_x, W.nblk_x * GCN_WAVES_PER_BLOCK, H, (double)d.Rn, W.bstats_x,
-                                                   G[8], G[9]);
-    GCN_CHECK_LAUNCH("k_bn_bwd_finalize(nodes)");
-    GCN_PROF_PRE("k_node_bwd_pre");
-    k_node_bwd_pre<<<elem_blocks(d.Rn * (H / 4)), 256, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.D, S.stats + 2 * H, S.stats + 3 * H,
-                                                                P[8], P[9], W.bstats_x, dx, W.dxtmp, W.qv, rng, 2 * sid + 1,
-                                                                p, training);
-    GCN_CHECK_LAUNCH("k_node_bwd_pre");
-    const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-    GCN_PROF_PRE("k_edge_bwd_main");
-    k_edge_bwd_main<MT><<<wave_blocks(units), GCN_BLOCK, 0, st>>>(d.B, d.V, d.C, H, d.IT, agg, de, S.e_tmp, P[4], S.Vn, S.A, W.qv,
-                                                                  S.stats, P[10], P[11], W.bstats_e, W.det, W.rowpart,
-                                                                  W.colVe, W.colVn, rng, 2 * sid, p, training);
-    GCN_CHECK_LAUNCH("k_edge_bwd_main");
-    GCN_PROF_PRE("k_node_bwd");
-    k_node_bwd<MT><<<wave_blocks((d.Rn + 15) / 16), GCN_BLOCK, 0, st>>>((int)d.Rn, H, d.njt, d.nit, W.rowpart, W.colVe,
-                                                                       W.colVn, W.dxtmp, P[0], P[2], P[6], dx, W.dVe, W.dVn);
-    GCN_CHECK_LAUNCH("k_node_bwd");
+    {
+        BnBwdFin fa = {};
+        fa.partial[0] = W.bpart_e; fa.nP[0] = npart_e; fa.n[0] = (double)d.Re; fa.bstats[0] = W.bstats_e; fa.dgamma[0] = G[10]; fa.dbeta[0] = G[11];
+        fa.partial[1] = W.bpart_x; fa.nP[1] = npart_x; fa.n[1] = (double)d.Rn; fa.bstats[1] = W.bstats_x; fa.dgamma[1] = G[8]; fa.dbeta[1] = G[9];
+        GCN_PROF_PRE("k_bn_bwd_finalize");
+        k_bn_bwd_finalize<<<dim3(H / 4, 2, 1), GCN_BLOCK, 0, st>>>(fa, H);
+        GCN_CHECK_LAUNCH("k_bn_bwd_finalize");
+    }
+    {
+        EdgeBwdArgs a = {};
+        a.B = d.B; a.V = d.V; a.C = d.C; a.H = H; a.IT = d.IT; a.mean_agg = agg;
+        a.de = de; a.e_tmp = S.e_tmp; a.WUt = wT[2];
+        a.Vn = S.Vn; a.Aagg = S.A; a.Dn = S.D; a.dx = dx; a.x_tmp = S.x_tmp; a.stats = S.stats;
+        a.gamma_e = P[10]; a.beta_e = P[11]; a.gamma_x = P[8]; a.beta_x = P[9];
+        a.bstats_e = W.bstats_e; a.bstats_x = W.bstats_x;
+        a.det_out = W.det; a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn;
+        a.rng = rng; a.sid_e = 2 * sid; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
+        if (nx.on) {
+            a.next.tmp = nx.e_tmp; a.next.mean = nx.stats; a.next.rstd = nx.stats + H; a.next.gamma = nx.gamma_e;
+            a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
+        }
+        const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
+        const int blocks = wave_blocks(units);
+        GCN_PROF_PRE("k_edge_bwd_main2");
+        k_edge_bwd_main2<MT><<<blocks, GCN_BLOCK, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_edge_bwd_main2");
+        if (nx.on) npart_e = blocks;
+    }
+    {
+        NodeBwdArgs a = {};
+        a.rows = (int)d.Rn; a.H = H; a.njt = d.njt; a.nit = d.nit;
+        a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn; a.dx = dx; a.x_tmp = S.x_tmp;
+        a.mean = S.stats + 2 * H; a.rstd = S.stats + 3 * H; a.gamma = P[8]; a.beta = P[9]; a.bstats = W.bstats_x;
+        a.WnUt = wT[0]; a.WnVt = wT[1]; a.WeVt = wT[3];
+        a.dxtmp_out = W.dxtmp; a.dVe_out = W.dVe; a.dVn_out = W.dVn;
+        a.rng = rng; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
+        if (nx.on) {
+            a.next.tmp = nx.x_tmp; a.next.mean = nx.stats + 2 * H; a.next.rstd = nx.stats + 3 * H; a.next.gamma = nx.gamma_x;
+            a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
+        }
+        const int blocks = wave_blocks((d.Rn + 15) / 16);
+        GCN_PROF_PRE("k_node_bwd2");
+        k_node_bwd2<MT><<<blocks, GCN_BLOCK, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_node_bwd2");
+        if (nx.on) npart_x = blocks;
+    }
     const int slab = H * H + H;
     {
         TnProblems pr = {};
@@ -248,31 +322,66 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
         GCN_PROF_PRE("k_gemm_tn(edges)");
         k_gemm_tn<MT><<<dim3(W.S_e, (MT + 3) / 4, 1), GCN_BLOCK, 0, st>>>(d.Re, H, 1, pr, W.tn_e);
         GCN_CHECK_LAUNCH("k_gemm_tn(edges)");
-        ReduceDst rd = {};
-        rd.n = 2; rd.dst[0] = G[4]; rd.dst[1] = G[5];
-        rd.off[0] = 0; rd.off[1] = H * H; rd.off[2] = slab;
-        GCN_PROF_PRE("k_reduce_slabs(edges)");
-        k_reduce_slabs<<<(slab + 255) / 256, 256, 0, st>>>(W.tn_e, W.S_e, slab, rd);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(edges)");
     }
     {
         TnProblems pr = {};
-        GCN_PROF_PRE("k_gemm_tn(nodes)");
         pr.X[0] = W.dxtmp; pr.Y[0] = x_in;   // node_feat.U
         pr.X[1] = W.dVn; pr.Y[1] = x_in;     // node_feat.V
         pr.X[2] = W.dVe; pr.Y[2] = x_in;     // edge_feat.V
+        GCN_PROF_PRE("k_gemm_tn(nodes)");
         k_gemm_tn<MT><<<dim3(W.S_n, (MT + 3) / 4, 3), GCN_BLOCK, 0, st>>>(d.Rn, H, 3, pr, W.tn_n);
         GCN_CHECK_LAUNCH("k_gemm_tn(nodes)");
-        ReduceDst rd = {};
+    }
+    {
+        ReduceJobs jobs = {};
+        jobs.n = 2;
+        jobs.job[0].partial = W.tn_e; jobs.job[0].nP = W.S_e; jobs.job[0].ncols = slab;
+        jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[4]; jobs.job[0].rd.dst[1] = G[5];
+        jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = H * H; jobs.job[0].rd.off[2] = slab;
+        jobs.job[1].partial = W.tn_n; jobs.job[1].nP = W.S_n; jobs.job[1].ncols = 3 * slab;
+        ReduceDst& rd = jobs.job[1].rd;
         rd.n = 6;
         rd.dst[0] = G[0]; rd.dst[1] = G[1]; rd.dst[2] = G[2]; rd.dst[3] = G[3]; rd.dst[4] = G[6]; rd.dst[5] = G[7];
         for (int k = 0; k < 3; ++k) { rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H; }
         rd.off[6] = 3 * slab;
-        GCN_PROF_PRE("k_reduce_slabs(nodes)");
-        k_reduce_slabs<<<(3 * slab + 255) / 256, 256, 0, st>>>(W.tn_n, W.S_n, 3 * slab, rd);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(nodes)");
+        GCN_PROF_PRE("k_reduce_slabs(layer)");
+        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+        GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
     }
     return 0;
+}
+
+template <int MT>
+int transpose_layer_weights(const float* const* P, float* wTbuf, const float** wT, int H, hipStream_t st) {
+    TransposeList tl = {};
+    const int idx[4] = {0, 2, 4, 6};     // node_feat.U, node_feat.V, edge_feat.U, edge_feat.V weights
+    for (int k = 0; k < 4; ++k) { tl.src[k] = P[idx[k]]; tl.dst[k] = wTbuf + (size_t)k * H * H; wT[k] = tl.dst[k]; }
+    GCN_PROF_PRE("k_transpose_weights");
+    k_transpose_weights<<<4, GCN_BLOCK, 0, st>>>(tl, H);
+    GCN_CHECK_LAUNCH("k_transpose_weights");
+    return 0;
+}
+
+// standalone layer backward: own statistics passes, no layer below
+template <int MT>
+int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
+                const float* x_in, const float* e_in, const float* const* P, const LayerSaved& S, float* dx,
+                float* de, float* const* G, const LayerBwdWs& W, float* wTbuf, hipStream_t st) {
+    const int H = d.H;
+    const float* wT[4];
+    if (int rc = transpose_layer_weights<MT>(P, wTbuf, wT, H, st)) return rc;
+    const int nblk_e = wave_blocks((d.Re + 15) / 16), nblk_x = wave_blocks((d.Rn + 15) / 16);
+    GCN_PROF_PRE("k_bn_bwd_stats(edges)");
+    k_bn_bwd_stats<MT><<<nblk_e, GCN_BLOCK, 0, st>>>(d.Re, H, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11], W.bpart_e, rng,
+                                                     2 * sid, p, training);
+    GCN_CHECK_LAUNCH("k_bn_bwd_stats(edges)");
+    GCN_PROF_PRE("k_bn_bwd_stats(nodes)");
+    k_bn_bwd_stats<MT><<<nblk_x, GCN_BLOCK, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9],
+                                                     W.bpart_x, rng, 2 * sid + 1, p, training);
+    GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
+    int npe = nblk_e, npx = nblk_x;
+    NextLayer none = {};
+    return layer_bwd_core<MT>(d, agg, p, training, rng, sid, x_in, e_in, P, wT, S, dx, de, G, W, npe, npx, none, st);
 }
 
 #define DISPATCH_MT(MTV, CALL)                                   \
@@ -287,20 +396,20 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
 // ---- model-level plans -----------------------------------------------------------------------------
 struct ModelPlan {
     Dims d;
-    int L, NHID, voc, nparams;
+    int L, NHID, voc, nparams, n_emb;
     size_t x_act, e_act, lsaved;    // float offsets inside `saved`
     size_t lsaved_each, total_saved;
 };
 ModelPlan make_plan(const gcn_model_desc* m) {
     ModelPlan p;
     p.d = make_dims(m->B, m->V, m->C, m->H);
-    p.L = m->L; p.NHID = m->mlp_layers - 1; p.voc = m->voc_out;
+    p.L = m->L; p.NHID = m->mlp_layers - 1; p.voc = m->voc_out; p.n_emb = m->n_emb;
     p.nparams = 3 + GCN_LAYER_NPARAMS * m->L + 2 * m->mlp_layers;
     const size_t nh = p.d.Rn * p.d.H, eh = p.d.Re * p.d.H;
     p.lsaved_each = layer_saved_floats(p.d);
-    p.x_act = 0;
-    p.e_act = p.x_act + (size_t)(p.L + 1) * nh;
-    p.lsaved = p.e_act + (size_t)(p.L + 1) * eh;
+    p.x_act = 0;                                   // x_act[l] = node input of layer l, l = 0..L-1
+    p.e_act = p.x_act + (size_t)p.L * nh;          // e_act[l] = edge input of layer l
+    p.lsaved = p.e_act + (size_t)p.L * eh;
     p.total_saved = p.lsaved + (size_t)p.L * p.lsaved_each;
     return p;
 }
@@ -308,6 +417,7 @@ int check_model(const gcn_model_desc* m) {
     if (m == nullptr) return fail(-1, "null model descriptor");
     if (int rc = check_dims(m->B, m->V, m->C, m->H)) return rc;
     if (m->L < 1) return fail(-1, "num_layers %d < 1", m->L);
+    if (m->L > 15) return fail(-1, "num_layers %d > 15 is not supported by this build", m->L);
     if (m->mlp_layers < 1 || m->mlp_layers > GCN_MAX_MLP_LAYERS) return fail(-1, "mlp_layers %d outside 1..%d", m->mlp_layers, GCN_MAX_MLP_LAYERS);
     if (m->voc_out != 1 && m->voc_out != 2) return fail(-1, "voc_edges_out %d must be 1 or 2", m->voc_out);
     if (m->H % 2 != 0) return fail(-1, "hidden_dim must be even");
@@ -330,7 +440,8 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
 }
 struct ModelBwdWs {
     LayerBwdWs lw;
-    float *de, *dx, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart;
+    float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
+    int* emb_cnt;
     int head_blk, S_h, emb_blk;
 };
 ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
@@ -339,6 +450,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     w.lw = carve_bwd_ws(p.d, b);
     w.de = b.f(eh);
     w.dx = b.f(p.d.Rn * p.d.H);
+    w.eL = p.NHID > 0 ? b.f(eh) : nullptr;         // output of the last conv layer, operand of the first MLP weight gradient
     // with one hidden layer the pre-activation stash aliases the layers' det buffer (the head finishes
     // before layer L-1 starts); deeper MLPs get NHID contiguous slabs of their own
     w.dpre_stash = p.NHID > 1 ? b.f((size_t)p.NHID * eh) : nullptr;
@@ -349,26 +461,29 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     w.tn_h = b.f((size_t)w.S_h * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));
     w.emb_blk = wave_blocks((p.d.Re + 15) / 16);
     w.embpart = b.f((size_t)w.emb_blk * GCN_WAVES_PER_BLOCK * p.d.H);
+    w.emb_g = b.f((size_t)p.d.B * p.d.V * p.d.H);
+    w.emb_cnt = (int*)b.raw((size_t)p.d.B * p.d.V * (size_t)p.n_emb * sizeof(int));
+    w.wT = b.f((size_t)(4 * p.L + p.NHID) * p.d.H * p.d.H);
     return w;
 }
 
 template <int MT, int NHID>
-void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const float* eL, const float* cap,
+void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const float* cap,
                      const long long* y_edges, const float* edge_cw, float* y_pred, float* loss_partial, int* counts,
                      const unsigned long long* rng, int blocks, hipStream_t st) {
-    k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, eL, cap, m->mask_invalid_edges,
+    k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
                                                         m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
                                                         m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp,
                                                         m->training);
 }
 template <int MT, int NHID>
-void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const float* eL, const float* cap,
-                     const long long* y_edges, const float* edge_cw, const float* loss_out, const float* dloss,
-                     const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
+void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const NextBn& next,
+                     float* e_stash, const float* cap, const long long* y_edges, const float* edge_cw, const float* loss_out,
+                     const float* dloss, const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
                      const unsigned long long* rng, int blocks, hipStream_t st) {
-    k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, eL, cap, m->mask_invalid_edges,
-                                                        m->has_labels ? y_edges : nullptr, edge_cw, loss_out, dloss, dy_pred, de,
-                                                        dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training);
+    k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, next, e_stash, cap,
+                                                        m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
+                                                        dloss, dy_pred, de, dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training);
 }
 
 #define DISPATCH_NHID(NH, CALL)                                  \
@@ -387,6 +502,22 @@ HeadParams head_params(const ModelPlan& p, const float* const* P) {
     hp.outW = P[base + 2 * p.NHID];
     hp.outB = P[base + 2 * p.NHID + 1];
     return hp;
+}
+
+PrevLayer prev_of(const ModelPlan& p, const float* saved, const float* const* P, int l) {
+    // description of layer l as the producer of layer l+1's (or the head's) inputs
+    const Dims& d = p.d;
+    const size_t nh = d.Rn * d.H, eh = d.Re * d.H;
+    const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
+    const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
+    PrevLayer pv = {};
+    pv.kind = 1;
+    pv.e_tmp = S.e_tmp; pv.x_tmp = S.x_tmp; pv.stats = S.stats;
+    pv.e_in = saved + p.e_act + (size_t)l * eh;
+    pv.x_in = saved + p.x_act + (size_t)l * nh;
+    pv.gamma_x = LP[8]; pv.beta_x = LP[9]; pv.gamma_e = LP[10]; pv.beta_e = LP[11];
+    pv.sid = l;
+    return pv;
 }
 
 }  // namespace
@@ -433,6 +564,7 @@ size_t gcn_layer_ws_bytes(int B, int V, int C, int H) {
     Bump f(nullptr, 0), b(nullptr, 0);
     carve_fwd_ws(d, f);
     carve_bwd_ws(d, b);
+    b.f((size_t)4 * H * H);
     return std::max(f.off, b.off);
 }
 
@@ -463,10 +595,11 @@ int gcn_layer_bwd(int B, int V, int C, int H, int aggregation, float p_drop, int
     const Dims d = make_dims(B, V, C, H);
     Bump b(ws, ws_bytes);
     const LayerBwdWs W = carve_bwd_ws(d, b);
+    float* wTbuf = b.f((size_t)4 * H * H);
     if (!b.ok()) return fail(-2, "gcn_layer_bwd: workspace too small (%zu < %zu bytes)", ws_bytes, b.off);
     const LayerSaved S = carve_saved(d, const_cast<float*>(saved));
     DISPATCH_MT(d.MT, return layer_bwd_t<MT>(d, aggregation, p_drop, training, rng, stream_id, x_in, e_in, params, S, dx, de,
-                                             grads, W, (hipStream_t)stream));
+                                             grads, W, wTbuf, (hipStream_t)stream));
     return 0;
 }
 
@@ -506,28 +639,31 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const size_t nh = d.Rn * H, eh = d.Re * H;
     float* x_act = saved + p.x_act;
     float* e_act = saved + p.e_act;
-    GCN_PROF_PRE("k_embed_edges");
-    k_embed_edges<<<elem_blocks(d.Re * (H / 4)), 256, 0, st>>>(d.Re * (size_t)(H / 4), d.C, H, cap, P[2], e_act);
-    GCN_CHECK_LAUNCH("k_embed_edges");
     GCN_PROF_PRE("k_embed_nodes");
     k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act);
     GCN_CHECK_LAUNCH("k_embed_nodes");
     for (int l = 0; l < p.L; ++l) {
         const LayerSaved S = carve_saved(d, saved + p.lsaved + (size_t)l * p.lsaved_each);
         const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
+        PrevLayer pv = {};
+        if (l == 0) { pv.kind = 2; pv.cap = cap; pv.we = P[2]; }
+        else pv = prev_of(p, saved, P, l - 1);
         int rc = 0;
-        DISPATCH_MT(d.MT, rc = layer_fwd_t<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, x_act + (size_t)l * nh,
-                                               e_act + (size_t)l * eh, LP, x_act + (size_t)(l + 1) * nh,
-                                               e_act + (size_t)(l + 1) * eh, S, W.lw, st));
+        // layer 0: x_act[0] was written by the embedding; later layers write their own input while applying layer l-1
+        DISPATCH_MT(d.MT, rc = layer_fwd_core<MT>(d, m->aggregation, m->p_layer, m->training, rng, pv, x_act + (size_t)l * nh,
+                                                  l == 0 ? nullptr : x_act + (size_t)l * nh, nullptr, e_act + (size_t)l * eh, LP, S,
+                                                  W.lw, st));
         if (rc) return rc;
     }
     const HeadParams hp = head_params(p, P);
     if (m->has_labels) {
         if (hipMemsetAsync(err_counts, 0, sizeof(int) * 2 * (size_t)d.B * d.C, st) != hipSuccess) return fail(-3, "memset failed");
     }
+    const PrevLayer last = prev_of(p, saved, P, p.L - 1);
+    const EdgeSrc src = make_edge_src(last, nullptr, nullptr, H, m->p_layer, m->training);
     GCN_PROF_PRE("k_head_fwd");
-    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, e_act + (size_t)p.L * eh, cap, y_edges, edge_cw,
-                                                                      y_pred, W.loss_partial, err_counts, rng, W.head_blk, st))));
+    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, src, cap, y_edges, edge_cw, y_pred,
+                                                                      W.loss_partial, err_counts, rng, W.head_blk, st))));
     GCN_CHECK_LAUNCH("k_head_fwd");
     if (m->has_labels) {
         GCN_PROF_PRE("k_loss_finalize");
@@ -553,56 +689,87 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     const ModelBwdWs W = carve_model_bwd(p, b);
     if (!b.ok()) return fail(-2, "gcn_model_bwd: workspace too small (%zu < %zu bytes)", ws_bytes, b.off);
     const int H = d.H;
-    const size_t nh = d.Rn * H, eh = d.Re * H;
+    const size_t nh = d.Rn * H, eh = d.Re * H, hh2 = (size_t)H * H;
     const float* x_act = saved + p.x_act;
     const float* e_act = saved + p.e_act;
     const HeadParams hp = head_params(p, P);
     const int hbase = 3 + GCN_LAYER_NPARAMS * p.L;
     const int slab = H * H + H;
-    GCN_PROF_PRE("k_head_bwd");
-    float* dpre_all = p.NHID == 1 ? W.lw.det : W.dpre_stash;   // [NHID][Re*H], see carve_model_bwd
-    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, e_act + (size_t)p.L * eh, cap, y_edges, edge_cw,
-                                                                      loss_out, dloss, dy_pred, W.de, dpre_all, W.h_stash,
-                                                                      W.wpartial, rng, W.head_blk, st))));
-    GCN_CHECK_LAUNCH("k_head_bwd");
+    // transposed copies of every H x H weight used in an "X * W" product of the backward pass
     {
-        const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
-        ReduceDst rd = {};
-        rd.n = 2; rd.dst[0] = G[hbase + 2 * p.NHID]; rd.dst[1] = G[hbase + 2 * p.NHID + 1];
-        rd.off[0] = 0; rd.off[1] = p.voc * H; rd.off[2] = p.voc * H + p.voc;
-        GCN_PROF_PRE("k_reduce_slabs(head out)");
-        k_reduce_slabs<<<(wcols + 255) / 256, 256, 0, st>>>(W.wpartial, W.head_blk * GCN_WAVES_PER_BLOCK, wcols, rd);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(head out)");
+        TransposeList tl = {};
+        int n = 0;
+        const int idx[4] = {0, 2, 4, 6};
+        for (int l = 0; l < p.L; ++l)
+            for (int k = 0; k < 4; ++k) { tl.src[n] = P[3 + GCN_LAYER_NPARAMS * l + idx[k]]; tl.dst[n] = W.wT + (size_t)n * hh2; ++n; }
+        GCN_PROF_PRE("k_transpose_weights");
+        k_transpose_weights<<<n, GCN_BLOCK, 0, st>>>(tl, H);
+        GCN_CHECK_LAUNCH("k_transpose_weights");
     }
+    float* dpre_all = p.NHID == 1 ? W.lw.det : W.dpre_stash;   // [NHID][Re*H], see carve_model_bwd
+    const PrevLayer last = prev_of(p, saved, P, p.L - 1);
+    const EdgeSrc src = make_edge_src(last, nullptr, nullptr, H, m->p_layer, m->training);
+    NextBn hnext = {};
+    hnext.tmp = last.e_tmp; hnext.mean = last.stats; hnext.rstd = last.stats + H; hnext.gamma = last.gamma_e; hnext.beta = last.beta_e;
+    hnext.drop_sid = 2 * last.sid; hnext.partial = W.lw.bpart_e;
+    GCN_PROF_PRE("k_head_bwd");
+    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
+                                                                      dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
+                                                                      W.head_blk, st))));
+    GCN_CHECK_LAUNCH("k_head_bwd");
+    int npart_e = W.head_blk, npart_x = 1;
     if (p.NHID > 0) {
         TnProblems pr = {};
         for (int k = 0; k < p.NHID; ++k) {
             pr.X[k] = dpre_all + (size_t)k * eh;
-            pr.Y[k] = k == 0 ? e_act + (size_t)p.L * eh : W.h_stash + (size_t)(k - 1) * eh;
+            pr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
         }
         GCN_PROF_PRE("k_gemm_tn(head)");
         DISPATCH_MT(d.MT, (k_gemm_tn<MT><<<dim3(W.S_h, (MT + 3) / 4, p.NHID), GCN_BLOCK, 0, st>>>(d.Re, H, p.NHID, pr, W.tn_h)));
         GCN_CHECK_LAUNCH("k_gemm_tn(head)");
-        ReduceDst rd = {};
-        rd.n = 2 * p.NHID;
-        for (int k = 0; k < p.NHID; ++k) {
-            rd.dst[2 * k] = G[hbase + 2 * k]; rd.dst[2 * k + 1] = G[hbase + 2 * k + 1];
-            rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H;
-        }
-        rd.off[2 * p.NHID] = p.NHID * slab;
-        GCN_PROF_PRE("k_reduce_slabs(head hidden)");
-        k_reduce_slabs<<<(p.NHID * slab + 255) / 256, 256, 0, st>>>(W.tn_h, W.S_h, p.NHID * slab, rd);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(head hidden)");
     }
-    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient is zero
+    {
+        const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
+        ReduceJobs jobs = {};
+        jobs.n = p.NHID > 0 ? 2 : 1;
+        jobs.job[0].partial = W.wpartial; jobs.job[0].nP = W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
+        jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[hbase + 2 * p.NHID]; jobs.job[0].rd.dst[1] = G[hbase + 2 * p.NHID + 1];
+        jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = p.voc * H; jobs.job[0].rd.off[2] = p.voc * H + p.voc;
+        int maxcols = wcols;
+        if (p.NHID > 0) {
+            jobs.job[1].partial = W.tn_h; jobs.job[1].nP = W.S_h; jobs.job[1].ncols = p.NHID * slab;
+            ReduceDst& rd = jobs.job[1].rd;
+            rd.n = 2 * p.NHID;
+            for (int k = 0; k < p.NHID; ++k) {
+                rd.dst[2 * k] = G[hbase + 2 * k]; rd.dst[2 * k + 1] = G[hbase + 2 * k + 1];
+                rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H;
+            }
+            rd.off[2 * p.NHID] = p.NHID * slab;
+            maxcols = std::max(maxcols, p.NHID * slab);
+        }
+        GCN_PROF_PRE("k_reduce_slabs(head)");
+        k_reduce_slabs<<<dim3((maxcols + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
+        GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
+    }
+    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient and the
+    // BatchNorm-backward sums derived from it are zero
     if (hipMemsetAsync(W.dx, 0, nh * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
+    if (hipMemsetAsync(W.lw.bpart_x, 0, 2 * (size_t)H * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
     for (int l = p.L - 1; l >= 0; --l) {
         const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
         const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
         float* const* LG = G + 3 + GCN_LAYER_NPARAMS * l;
+        const float* wT[4];
+        for (int k = 0; k < 4; ++k) wT[k] = W.wT + (size_t)(4 * l + k) * hh2;
+        NextLayer nx = {};
+        if (l > 0) {
+            const PrevLayer below = prev_of(p, saved, P, l - 1);
+            nx.on = true; nx.e_tmp = below.e_tmp; nx.x_tmp = below.x_tmp; nx.stats = below.stats;
+            nx.gamma_x = below.gamma_x; nx.beta_x = below.beta_x; nx.gamma_e = below.gamma_e; nx.beta_e = below.beta_e; nx.sid = l - 1;
+        }
         int rc = 0;
-        DISPATCH_MT(d.MT, rc = layer_bwd_t<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, x_act + (size_t)l * nh,
-                                               e_act + (size_t)l * eh, LP, S, W.dx, W.de, LG, W.lw, st));
+        DISPATCH_MT(d.MT, rc = layer_bwd_core<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, x_act + (size_t)l * nh,
+                                                  e_act + (size_t)l * eh, LP, wT, S, W.dx, W.de, LG, W.lw, npart_e, npart_x, nx, st));
         if (rc) return rc;
     }
     // embeddings
@@ -610,23 +777,25 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     DISPATCH_MT(d.MT, (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
     GCN_CHECK_LAUNCH("k_embed_bwd_edges");
     {
-        ReduceDst rd = {};
-        rd.n = 1; rd.dst[0] = G[2]; rd.off[0] = 0; rd.off[1] = H;
+        ReduceJobs jobs = {};
+        jobs.n = 1;
+        jobs.job[0].partial = W.embpart; jobs.job[0].nP = W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = H;
+        jobs.job[0].rd.n = 1; jobs.job[0].rd.dst[0] = G[2]; jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = H;
         GCN_PROF_PRE("k_reduce_slabs(edge embedding)");
-        k_reduce_slabs<<<(H + 255) / 256, 256, 0, st>>>(W.embpart, W.emb_blk * GCN_WAVES_PER_BLOCK, H, rd);
+        k_reduce_slabs<<<dim3((H + 15) / 16, 1, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(edge embedding)");
     }
     {
-        const int hh = H / 2;
-        const int threads = std::max(64, std::min(256, (256 / hh) * hh >= hh ? 256 : hh));
+        GCN_PROF_PRE("k_embed_bwd_rowsum");
+        k_embed_bwd_rowsum<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt);
+        GCN_CHECK_LAUNCH("k_embed_bwd_rowsum");
         GCN_PROF_PRE("k_embed_bwd_nodes");
-        k_embed_bwd_nodes<<<m->n_emb + 1, threads, threads * sizeof(double), st>>>(d.B, d.V, d.C, H, m->n_emb, x_nodes, demand,
-                                                                                W.dx, G[0], G[1]);
+        k_embed_bwd_nodes<<<m->n_emb + 1, GCN_BLOCK, GCN_BLOCK * sizeof(double), st>>>(d.B * d.V, d.C, H, m->n_emb, W.emb_g,
+                                                                                    W.emb_cnt, G[0], G[1]);
         GCN_CHECK_LAUNCH("k_embed_bwd_nodes");
     }
     return 0;
 }
-
 
 // ---- beam search ---------------------------------------------------------------------------------
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {

@@ -107,12 +107,17 @@ __device__ __forceinline__ Tile<MT> tile_gemm(const Tile<MT>& in, const WFrag<MT
     return out;
 }
 
-// Sum over the 16 row slots; every lane of the 16-lane group ends up with the total.
+// Sum over the 16 row slots with DPP row rotations (one VALU op per step, no LDS crossbar);
+// every lane of the 16-lane group ends up with the total.
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float red16(float x) {
-    x += __shfl_xor(x, 1, GCN_WAVE);
-    x += __shfl_xor(x, 2, GCN_WAVE);
-    x += __shfl_xor(x, 4, GCN_WAVE);
-    x += __shfl_xor(x, 8, GCN_WAVE);
+    x += dpp_row_ror<8>(x);
+    x += dpp_row_ror<4>(x);
+    x += dpp_row_ror<2>(x);
+    x += dpp_row_ror<1>(x);
     return x;
 }
 template <int MT>
@@ -129,7 +134,8 @@ __device__ __forceinline__ float redq(float x) {
     return x;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid through the hardware exp2 / rcp (each ~1 ulp): |error| < 3e-7, far inside the 1e-4 parity budget
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------- counter-based dropout
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -181,4 +187,62 @@ __device__ __forceinline__ ChanVec<MT> chan_load(const float* __restrict__ p, in
         c.v[m] = (p != nullptr && col < H) ? *reinterpret_cast<const f32x4*>(p + col) : f4zero();
     }
     return c;
+}
+
+// ---------------------------------------------------------------- weights / channel constants in LDS
+// Fragment-linear image of a weight matrix: fragment (m, s) occupies 64 consecutive float4, one per lane,
+// so a wavefront reads it with one conflict-free ds_read_b128.  MT*MT*1 KiB per matrix.
+template <int MT, bool TRANSPOSED>
+__device__ __forceinline__ void wlds_fill(f32x4* __restrict__ dst, const float* __restrict__ W, int H) {
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int f = wv; f < MT * MT; f += nwv) {
+        const int m = f / MT, s = f - m * MT;
+        f32x4 v;
+        if (!TRANSPOSED) {
+            const int n = 16 * m + rs, k = 16 * s + 4 * q;
+            v = (n < H && k < H) ? *reinterpret_cast<const f32x4*>(W + (size_t)n * H + k) : f4zero();
+        } else {
+            const int kout = 16 * m + rs;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 16 * s + 4 * q + t;
+                v[t] = (kout < H && n < H) ? W[(size_t)n * H + kout] : 0.f;
+            }
+        }
+        dst[f * 64 + lane] = v;
+    }
+}
+template <int MT>
+__device__ __forceinline__ Tile<MT> tile_gemm_lds(const Tile<MT>& in, const f32x4* __restrict__ wl, int lane) {
+    Tile<MT> out;
+    tile_zero(out);
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+        f32x4 w[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) w[m] = wl[(m * MT + s) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                out.v[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[m][t], in.v[s][t], out.v[m], 0, 0, 0);
+    }
+    return out;
+}
+// Returns 0 through an opaque register.  Adding it to an LDS index inside a loop keeps the compiler from
+// hoisting loop-invariant LDS reads (weights, channel constants) into registers for the whole kernel,
+// which would cost hundreds of VGPRs and the occupancy the LDS staging is meant to buy.
+__device__ __forceinline__ int lds_opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
+// Channel constants: nvec vectors of H floats copied into LDS rows of HP = 16*MT floats (zero padded).
+__device__ __forceinline__ void clds_fill(float* __restrict__ dst, const float* __restrict__ src, int H, int HP) {
+    for (int t = threadIdx.x; t < HP; t += blockDim.x) dst[t] = (src != nullptr && t < H) ? src[t] : 0.f;
+}
+__device__ __forceinline__ f32x4 clds_get(const float* __restrict__ row, int m, int q) {
+    return *reinterpret_cast<const f32x4*>(row + 16 * m + 4 * q);
 }

@@ -8,7 +8,7 @@
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward, reduction pass.  For out = dropout(relu(BN(tmp)) + resid):
 //   dpre = dnew * dropmask ; dbn = dpre * [BN(tmp) > 0] ; xhat = (tmp - mean) * rstd
-// accumulates per channel sum(dbn) and sum(dbn * xhat) into partial[nwaves][2][H].
+// accumulates per channel sum(dbn) and sum(dbn * xhat) into partial[nblocks][2][H].
 // Used for the edge tensor (R_e rows) and the node tensor (R_n rows).
 // ------------------------------------------------------------------------------------------------
 template <int MT>
@@ -47,35 +47,49 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_stats(
     }
     tile_red16(a1);
     tile_red16(a2);
+    // workgroup partial = sum of its 4 wavefronts, in wavefront order (LDS), one slab per workgroup
+    __shared__ float red[GCN_WAVES_PER_BLOCK][2][16 * MT];
+    const int wv = threadIdx.x >> 6;
     if (rs == 0) {
-        float* pp = partial + (size_t)wave * 2 * H;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int col = 16 * m + 4 * q;
-            if (col < H) {
-                *reinterpret_cast<f32x4*>(pp + col) = a1.v[m];
-                *reinterpret_cast<f32x4*>(pp + H + col) = a2.v[m];
-            }
+            *reinterpret_cast<f32x4*>(&red[wv][0][16 * m + 4 * q]) = a1.v[m];
+            *reinterpret_cast<f32x4*>(&red[wv][1][16 * m + 4 * q]) = a2.v[m];
         }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * H; t += blockDim.x) {
+        const int which = t / H, col = t - which * H;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < GCN_WAVES_PER_BLOCK; ++w2) v += red[w2][which][col];
+        partial[(size_t)blockIdx.x * 2 * H + t] = v;
     }
 }
 
 // partial [nP][2][H] -> bstats [2][H] = mean(dbn), mean(dbn*xhat); dgamma = sum(dbn*xhat), dbeta = sum(dbn).
-// grid = H/4.
-__global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_finalize(const float* __restrict__ partial, int nP, int H, double n,
-                                                              float* __restrict__ bstats, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+// grid = (H/4, 2): blockIdx.y = 0 edges, 1 nodes.
+struct BnBwdFin {
+    const float* partial[2];
+    int nP[2];
+    double n[2];
+    float* bstats[2];
+    float* dgamma[2];
+    float* dbeta[2];
+};
+__global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_finalize(BnBwdFin a, int H) {
     __shared__ double lds[GCN_BLOCK * 4];
     const int col = blockIdx.x * 4;
+    const int w = blockIdx.y;
     double s1[4], s2[4];
-    block_colsum4(partial, nP, 2 * H, col, s1, lds);
-    block_colsum4(partial, nP, 2 * H, H + col, s2, lds);
+    block_colsum4(a.partial[w], a.nP[w], 2 * H, col, s1, lds);
+    block_colsum4(a.partial[w], a.nP[w], 2 * H, H + col, s2, lds);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 4; ++k) {
-            bstats[col + k] = (float)(s1[k] / n);
-            bstats[H + col + k] = (float)(s2[k] / n);
-            dbeta[col + k] = (float)s1[k];
-            dgamma[col + k] = (float)s2[k];
+            a.bstats[w][col + k] = (float)(s1[k] / a.n[w]);
+            a.bstats[w][H + col + k] = (float)(s2[k] / a.n[w]);
+            a.dbeta[w][col + k] = (float)s1[k];
+            a.dgamma[w][col + k] = (float)s2[k];
         }
     }
 }
@@ -311,18 +325,38 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_gemm_tn(size_t rows, int H, int n
     float bsum = 0.f;
     const int n = 16 * m + rs;
     if (m < MT) {
-        for (size_t tile = t0; tile < t1; ++tile) {
+        // operands of one 16-row tile: a[st] = X[row(st)][n], b[st][k] = Y[row(st)][16k + rs], row(st) = 16*tile + 4*st + q
+        float a_cur[4], b_cur[4][MT], a_nxt[4], b_nxt[4][MT];
+        auto load_tile = [&](size_t tile, float (&a)[4], float (&b)[4][MT]) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const size_t row = tile * 16 + st * 4 + q;
                 const bool valid = row < rows;
-                const float a = (valid && n < H) ? X[row * H + n] : 0.f;
-                bsum += a;
+                a[st] = (valid && n < H) ? X[row * H + n] : 0.f;
 #pragma unroll
                 for (int k = 0; k < MT; ++k) {
                     const int kc = 16 * k + rs;
-                    const float bval = (valid && kc < H) ? Y[row * H + kc] : 0.f;
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[k], 0, 0, 0);
+                    b[st][k] = (valid && kc < H) ? Y[row * H + kc] : 0.f;
+                }
+            }
+        };
+        if (t0 < t1) load_tile(t0, a_cur, b_cur);
+        for (size_t tile = t0; tile < t1; ++tile) {
+            const bool more = tile + 1 < t1;
+            if (more) load_tile(tile + 1, a_nxt, b_nxt);      // in flight while this tile's MFMAs run
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                bsum += a_cur[st];
+#pragma unroll
+                for (int k = 0; k < MT; ++k)
+                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[st], b_cur[st][k], acc[k], 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    a_cur[st] = a_nxt[st];
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) b_cur[st][k] = b_nxt[st][k];
                 }
             }
         }
@@ -340,20 +374,58 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_gemm_tn(size_t rows, int H, int n
     }
 }
 
-// Sum of nP partial slabs of ncols floats -> up to 8 destination tensors: column range
-// [off[d], off[d+1]) of the slab goes to dst[d].  Fixed order, fp32 pairwise-free serial sum in fp64.
+// Sum of nP partial slabs of ncols floats (ncols % 4 == 0) -> up to 8 destination tensors: column range
+// [off[d], off[d+1]) of the slab goes to dst[d].  One workgroup per 16 columns: thread (pg, cg) adds
+// slabs pg, pg + 64, ... of float4 column group cg in fp64, then a fixed LDS tree over the 64 pg's, so
+// the result does not depend on scheduling.
 struct ReduceDst {
     float* dst[8];
     int off[9];
     int n;
 };
-__global__ void k_reduce_slabs(const float* __restrict__ partial, int nP, int ncols, ReduceDst rd) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    double s = 0;
-    for (int p = 0; p < nP; ++p) s += partial[(size_t)p * ncols + col];
-    for (int d = 0; d < rd.n; ++d)
-        if (col >= rd.off[d] && col < rd.off[d + 1]) { rd.dst[d][col - rd.off[d]] = (float)s; break; }
+struct ReduceJob {
+    const float* partial;
+    int nP, ncols;
+    ReduceDst rd;
+};
+struct ReduceJobs {
+    ReduceJob job[2];
+    int n;
+};
+// grid = (ceil(max ncols / 16), number of jobs)
+__global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
+    __shared__ double lds[64 * 16];
+    const ReduceJob& J = jobs.job[blockIdx.y];
+    const float* __restrict__ partial = J.partial;
+    const int nP = J.nP, ncols = J.ncols;
+    const int cg = threadIdx.x & 3, pg = threadIdx.x >> 2;
+    const int col = blockIdx.x * 16 + cg * 4;
+    if (blockIdx.x * 16 >= ncols) return;          // uniform per workgroup
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (col < ncols) {
+        for (int p = pg; p < nP; p += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)p * ncols + col);
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+        }
+    }
+    double* my = lds + pg * 16 + cg * 4;
+    my[0] = a0; my[1] = a1; my[2] = a2; my[3] = a3;
+    __syncthreads();
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        if (pg < sft) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) my[k] += my[sft * 16 + k];
+        }
+        __syncthreads();
+    }
+    if (pg == 0 && col < ncols) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = col + k;
+            for (int d = 0; d < J.rd.n; ++d)
+                if (cc >= J.rd.off[d] && cc < J.rd.off[d + 1]) { J.rd.dst[d][cc - J.rd.off[d]] = (float)my[k]; break; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,13 +438,20 @@ __global__ void k_reduce_slabs(const float* __restrict__ partial, int nP, int nc
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NHID>
 __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
-    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ e,
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, NextBn next, float* __restrict__ e_stash,
     const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
     const float* __restrict__ edge_cw, const float* __restrict__ loss_out /* [1] = sum w */,
     const float* __restrict__ dloss, const float* __restrict__ dy_pred,
     float* __restrict__ de, float* __restrict__ dpre_stash /* [NHID][rows*H] */,
     float* __restrict__ h_stash /* [NHID-1][rows*H] */, float* __restrict__ wpartial,
     const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][16 * MT];
+    __shared__ __attribute__((aligned(16))) float nred[GCN_WAVES_PER_BLOCK][2][16 * MT];
+    edge_src_fill_consts<MT>(cl, src, H);
+    for (int t = threadIdx.x; t < GCN_WAVES_PER_BLOCK * 2 * 16 * MT; t += blockDim.x) (&nred[0][0][0])[t] = 0.f;
+    __syncthreads();
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const bool do_next = next.tmp != nullptr;
     const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
     const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
@@ -392,7 +471,8 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
         const bool valid = row < rows;
         Tile<MT> h[NHID + 1];
         Tile<MT> dmul[NHID > 0 ? NHID : 1];   // relu' * dropout multiplier per hidden layer
-        h[0] = tile_load<MT>(valid ? e + row * H : nullptr, H, q);
+        h[0] = edge_src_tile<MT>(src, cl, sdc, row, valid, H, C, q, nullptr, nullptr, nullptr);
+        if (e_stash != nullptr) tile_store(valid ? e_stash + row * H : nullptr, H, q, h[0]);   // operand of the d W_0 GEMM
 #pragma unroll
         for (int k = 0; k < NHID; ++k) {
             WFrag<MT> wf;
@@ -462,6 +542,18 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
             dh = tile_gemm(dh, wf);
         }
         tile_store(valid ? de + row * H : nullptr, H, q, dh);
+        // BatchNorm-backward statistics of the last conv layer, whose apply was fused into this kernel's input
+        if (do_next) next_bn_accumulate<MT>(next, cl, nred[threadIdx.x >> 6], sdc, dh, row, valid, H, rs, q);
+    }
+    if (do_next) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * H; t += blockDim.x) {
+            const int which = t / H, col = t - which * H;
+            float v = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < GCN_WAVES_PER_BLOCK; ++w2) v += nred[w2][which][col];
+            next.partial[(size_t)blockIdx.x * 2 * H + t] = v;
+        }
     }
     tile_red16(dw2a);
     tile_red16(dw2b);
@@ -516,51 +608,62 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int 
     }
 }
 
-// Node embedding backward, one workgroup per embedding row v (blockIdx.x < n_emb) plus one extra
-// workgroup (blockIdx.x == n_emb) for d w_c.  Fixed-order LDS tree, so reproducible.
-//   dEmb[v][h] = (1/C) * sum_{b,i} count_v(b,i) * sum_c dx0[b,i,c,h]
-//   d w_c[h]   = sum_{b,i,c} demand[b,c] * dx0[b,i,c,H/2+h]
-__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_nodes(int B, int V, int C, int H, int n_emb,
-                                                              const long long* __restrict__ x_nodes,
-                                                              const float* __restrict__ demand,
-                                                              const float* __restrict__ dx0,
-                                                              float* __restrict__ demb, float* __restrict__ dwc) {
+// Node embedding backward in two small launches.
+//   k_embed_bwd_rowsum: per (b, i): g1[bi][h] = sum_c dx0[bi,c,h], g2[bi][h] = sum_c demand[b,c] * dx0[bi,c,H/2+h]
+//                       and cnt[bi][v] = #{c : x_nodes[bi,c] == v}
+//   k_embed_bwd_nodes : dEmb[v][h] = (1/C) * sum_bi cnt[bi][v] * g1[bi][h];  d w_c[h] = sum_bi g2[bi][h]
+// (x0[b,i,c,:H/2] is the mean over c' of Emb[x_nodes[b,i,c']], gcn_model.py:78-84).  Fixed summation
+// order, so reproducible.
+__global__ void k_embed_bwd_rowsum(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
+                                   const float* __restrict__ demand, const float* __restrict__ dx0,
+                                   float* __restrict__ g, int* __restrict__ cnt) {
+    const int bi = blockIdx.x, b = bi / V, hh = H / 2;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        float s = 0.f;
+        if (h < hh) {
+            for (int c = 0; c < C; ++c) s += dx0[((size_t)bi * C + c) * H + h];
+        } else {
+            for (int c = 0; c < C; ++c) s += demand[(size_t)b * C + c] * dx0[((size_t)bi * C + c) * H + h];
+        }
+        g[(size_t)bi * H + h] = s;
+    }
+    for (int v = threadIdx.x; v < n_emb; v += blockDim.x) {
+        int n = 0;
+        for (int c = 0; c < C; ++c) {
+            long long idx = x_nodes[(size_t)bi * C + c];
+            idx = idx < 0 ? 0 : (idx >= n_emb ? n_emb - 1 : idx);
+            n += (idx == v);
+        }
+        cnt[(size_t)bi * n_emb + v] = n;
+    }
+}
+
+// one workgroup per embedding row v (blockIdx.x < n_emb) plus one (blockIdx.x == n_emb) for d w_c
+__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
+                                                              const int* __restrict__ cnt, float* __restrict__ demb,
+                                                              float* __restrict__ dwc) {
     extern __shared__ double lds_d[];     // [blockDim.x]
     const int hh = H / 2;
     const int v = blockIdx.x;
-    const int nbi = B * V;
-    // thread layout: tid = part * hh + h, parts = blockDim.x / hh
     const int parts = blockDim.x / hh;
     const int h = threadIdx.x % hh, part = threadIdx.x / hh;
     double acc = 0;
     if (part < parts) {
         for (int bi = part; bi < nbi; bi += parts) {
             if (v < n_emb) {
-                int cnt = 0;
-                for (int c = 0; c < C; ++c) {
-                    long long idx = x_nodes[(size_t)bi * C + c];
-                    idx = idx < 0 ? 0 : (idx >= n_emb ? n_emb - 1 : idx);
-                    cnt += (idx == v);
-                }
-                if (cnt) {
-                    float s = 0.f;
-                    for (int c = 0; c < C; ++c) s += dx0[((size_t)bi * C + c) * H + h];
-                    acc += (double)cnt * (double)s;
-                }
+                const int n = cnt[(size_t)bi * n_emb + v];
+                if (n) acc += (double)n * (double)g[(size_t)bi * H + h];
             } else {
-                const int b = bi / V;
-                float s = 0.f;
-                for (int c = 0; c < C; ++c) s += demand[(size_t)b * C + c] * dx0[((size_t)bi * C + c) * H + hh + h];
-                acc += (double)s;
+                acc += (double)g[(size_t)bi * H + hh + h];
             }
         }
     }
     lds_d[threadIdx.x] = (part < parts) ? acc : 0.0;
     __syncthreads();
     if (part == 0) {
-        double s = 0;
-        for (int k = 0; k < parts; ++k) s += lds_d[k * hh + h];
-        if (v < n_emb) demb[(size_t)v * hh + h] = (float)(s / (double)C);
-        else dwc[h] = (float)s;
+        double sacc = 0;
+        for (int k = 0; k < parts; ++k) sacc += lds_d[k * hh + h];
+        if (v < n_emb) demb[(size_t)v * hh + h] = (float)(sacc / (double)C);
+        else dwc[h] = (float)sacc;
     }
 }

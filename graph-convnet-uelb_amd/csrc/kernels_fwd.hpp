@@ -2,6 +2,7 @@
 // Shapes: R_e = B*V*V*C edge rows laid out [B][V_i][V_j][C][H], R_n = B*V*C node rows [B][V][C][H].
 #pragma once
 #include "common.hpp"
+#include "kernels_fused.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // Embedding stage.  Mirrors ResidualGatedGCNModel.forward, src/gcn/models/gcn_model.py:68-84.
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_node_gemm3(
 //   num  += gate * Vn[b,j,c] ; den += gate                     (NodeFeatures.forward, :65-69)
 // then x_tmp[b,i,c] = Ux + num / (1e-20 + den) ("mean") or Ux + num ("sum"), and per-wavefront partial
 // sums of e_tmp, e_tmp^2, x_tmp, x_tmp^2 per channel for the two BatchNorms (:122-123).
-// partial layout: [nwaves][4][H].
+// partial layout: [nblocks][4][H].
 // ------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(GCN_BLOCK) void k_edge_fwd(
@@ -170,18 +171,25 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_edge_fwd(
     }
     tile_red16(s1);
     tile_red16(s2);
+    // workgroup partial = sum of its 4 wavefronts in wavefront order (through LDS): one slab per workgroup
+    __shared__ float red[GCN_WAVES_PER_BLOCK][4][16 * MT];
+    const int wv = threadIdx.x >> 6;
     if (rs == 0) {
-        float* p = partial + (size_t)wave * 4 * H;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int col = 16 * m + 4 * q;
-            if (col < H) {
-                *reinterpret_cast<f32x4*>(p + col) = s1.v[m];
-                *reinterpret_cast<f32x4*>(p + H + col) = s2.v[m];
-                *reinterpret_cast<f32x4*>(p + 2 * H + col) = sx1.v[m];
-                *reinterpret_cast<f32x4*>(p + 3 * H + col) = sx2.v[m];
-            }
+            *reinterpret_cast<f32x4*>(&red[wv][0][16 * m + 4 * q]) = s1.v[m];
+            *reinterpret_cast<f32x4*>(&red[wv][1][16 * m + 4 * q]) = s2.v[m];
+            *reinterpret_cast<f32x4*>(&red[wv][2][16 * m + 4 * q]) = sx1.v[m];
+            *reinterpret_cast<f32x4*>(&red[wv][3][16 * m + 4 * q]) = sx2.v[m];
         }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * H; t += blockDim.x) {
+        const int which = t / H, col = t - which * H;
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < GCN_WAVES_PER_BLOCK; ++w2) v += red[w2][which][col];
+        partial[(size_t)blockIdx.x * 4 * H + t] = v;
     }
 }
 
@@ -271,6 +279,7 @@ __global__ void k_bn_apply(size_t rows, int H, const float* __restrict__ tmp, co
 // edges (gcn_model.py:97-110); loss_edges (model_utils.py:51-78): log_softmax over the 2 classes and
 // class-weighted NLL partial sums (sum w*nll, sum w); edge_error counters (model_utils.py:255-308)
 // per (b, c): #(pred == y and mask), #mask with mask = (y + pred) > 0.
+// The input tile comes through EdgeSrc (plain read, or the fused apply of the last conv layer).
 // hidW/hidB: NHID pointers each.  loss_partial: [nwaves][2].  counts: [2][B*C] int32 (zeroed by caller).
 // ------------------------------------------------------------------------------------------------
 struct HeadParams {
@@ -282,10 +291,14 @@ struct HeadParams {
 
 template <int MT, int NHID>
 __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
-    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ e,
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src,
     const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
     const float* __restrict__ edge_cw, float* __restrict__ logits, float* __restrict__ loss_partial,
     int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][16 * MT];
+    edge_src_fill_consts<MT>(cl, src, H);
+    __syncthreads();
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
     const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
     const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
     for (size_t tile = wave; tile < ntiles; tile += nwaves) {
         const size_t row = tile * 16 + rs;
         const bool valid = row < rows;
-        Tile<MT> h = tile_load<MT>(valid ? e + row * H : nullptr, H, q);
+        Tile<MT> h = edge_src_tile<MT>(src, cl, sdc, row, valid, H, C, q, nullptr, nullptr, nullptr);
 #pragma unroll
         for (int k = 0; k < NHID; ++k) {
             WFrag<MT> wf;
