@@ -797,6 +797,49 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     return 0;
 }
 
+// ---- stand-alone loss / edge error -----------------------------------------------------------------
+size_t gcn_loss_ws_bytes(int B, int V, int C) {
+    if (B <= 0 || V <= 0 || C <= 0) return 0;
+    return align_up((size_t)kMaxPartBlocks * 2 * sizeof(float)) + align_up(2 * (size_t)B * C * sizeof(int));
+}
+
+int gcn_loss_edges_fwd(int B, int V, int C, const float* logits, const long long* y_edges, const float* edge_cw,
+                       float* loss_out, unsigned char* err_flags, void* ws, size_t ws_bytes, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0) return fail(-1, "gcn_loss_edges_fwd: non-positive dimension");
+    if (!logits || !y_edges || !loss_out || !err_flags || !ws) return fail(-1, "gcn_loss_edges_fwd: null pointer argument");
+    if (ws_bytes < gcn_loss_ws_bytes(B, V, C)) return fail(-2, "gcn_loss_edges_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Bump b(ws, ws_bytes);
+    float* part = b.f((size_t)kMaxPartBlocks * 2);
+    int* counts = (int*)b.raw(2 * (size_t)B * C * sizeof(int));
+    const size_t rows = (size_t)B * V * V * C;
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>((rows + GCN_BLOCK - 1) / GCN_BLOCK, kMaxPartBlocks));
+    if (hipMemsetAsync(counts, 0, 2 * (size_t)B * C * sizeof(int), st) != hipSuccess) return fail(-3, "memset failed");
+    GCN_PROF_PRE("k_loss_edges_fwd");
+    k_loss_edges_fwd<<<blocks, GCN_BLOCK, 0, st>>>(rows, V * V * C, C, logits, y_edges, edge_cw, edge_cw ? part : nullptr, counts, B * C);
+    GCN_CHECK_LAUNCH("k_loss_edges_fwd");
+    if (!edge_cw) {
+        // edge error only: give the finalizer zero-weight partials (loss comes out as NaN and is ignored)
+        if (hipMemsetAsync(part, 0, (size_t)blocks * 2 * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
+    }
+    GCN_PROF_PRE("k_loss_finalize");
+    k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(part, blocks, counts, B * C, loss_out, err_flags);
+    GCN_CHECK_LAUNCH("k_loss_finalize");
+    return 0;
+}
+
+int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long* y_edges, const float* edge_cw,
+                       const float* loss_out, const float* dloss, float* dlogits, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0) return fail(-1, "gcn_loss_edges_bwd: non-positive dimension");
+    if (!logits || !y_edges || !edge_cw || !loss_out || !dlogits) return fail(-1, "gcn_loss_edges_bwd: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)B * V * V * C;
+    GCN_PROF_PRE("k_loss_edges_bwd");
+    k_loss_edges_bwd<<<elem_blocks(rows), 256, 0, st>>>(rows, logits, y_edges, edge_cw, loss_out, dloss, dlogits);
+    GCN_CHECK_LAUNCH("k_loss_edges_bwd");
+    return 0;
+}
+
 // ---- beam search ---------------------------------------------------------------------------------
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
     (void)C; (void)K;
@@ -847,6 +890,23 @@ int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, 
     GCN_PROF_PRE("k_beam_scores");
     }
     GCN_CHECK_LAUNCH("k_beam_scores");
+    return 0;
+}
+
+
+// usage_ws: B*V*V int32 of scratch.  max_lf: float [B].  complete: uint8 [B*C].
+int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
+                    const long long* comm, int* usage_ws, float* max_lf, unsigned char* complete, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || PL <= 0) return fail(-1, "gcn_load_factor: non-positive dimension");
+    if (!paths || !path_len || !cap || !comm || !usage_ws || !max_lf || !complete) return fail(-1, "gcn_load_factor: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(usage_ws, 0, (size_t)B * V * V * sizeof(int), st) != hipSuccess) return fail(-3, "memset failed");
+    GCN_PROF_PRE("k_path_usage");
+    k_path_usage<<<elem_blocks((size_t)B * C * PL), 256, 0, st>>>(B, V, C, PL, paths, path_len, comm, usage_ws, complete);
+    GCN_CHECK_LAUNCH("k_path_usage");
+    GCN_PROF_PRE("k_max_load_factor");
+    k_max_load_factor<<<B, 256, 0, st>>>(V, usage_ws, cap, max_lf);
+    GCN_CHECK_LAUNCH("k_max_load_factor");
     return 0;
 }
 

@@ -295,3 +295,49 @@ __global__ void k_beam_scores_over_j(int B, int V, int C, const float* __restric
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Load factor of decoded paths, kept on the GPU right behind the beam search.
+// Restates mean_feasible_load_factor (src/common/graph/graph_utils.py:90-192): the demand of every
+// commodity is added along the edges of its path (integers, so the order of the atomic adds does not
+// matter), load = usage / capacity, +inf where a zero-capacity edge carries demand, 0 where an unused
+// edge has zero capacity; max_lf[b] is the maximum over the graph's edges.  Also reports, per commodity,
+// whether its path ends on the destination (Evaluator._compute_completion_and_approx,
+// src/gcn/train/evaluator.py:45-52).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_path_usage(int B, int V, int C, int PL, const int* __restrict__ paths, const int* __restrict__ path_len,
+                             const long long* __restrict__ comm, int* __restrict__ usage, unsigned char* __restrict__ complete) {
+    const size_t n = (size_t)B * C * PL;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = t / PL;
+        const int k = (int)(t - bc * PL);
+        const int len = path_len[bc];
+        const int b = (int)(bc / C);
+        const int* p = paths + bc * PL;
+        if (k == 0) complete[bc] = (len > 0 && p[len - 1] == (int)comm[bc * 3 + 1]) ? 1 : 0;
+        if (k + 1 < len) {
+            const int u = p[k], v = p[k + 1];
+            if (u >= 0 && u < V && v >= 0 && v < V) atomicAdd(&usage[((size_t)b * V + u) * V + v], (int)comm[bc * 3 + 2]);
+        }
+    }
+}
+// one workgroup per graph
+__global__ __launch_bounds__(256) void k_max_load_factor(int V, const int* __restrict__ usage, const float* __restrict__ cap,
+                                                        float* __restrict__ max_lf) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < V * V; t += blockDim.x) {
+        const int u = usage[(size_t)b * V * V + t];
+        const float c = cap[(size_t)b * V * V + t];
+        const float lf = c == 0.f ? (u == 0 ? 0.f : INFINITY) : (float)u / c;
+        m = fmaxf(m, lf);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) max_lf[b] = red[0];
+}

@@ -667,3 +667,62 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_nodes(int nbi, int C, i
         else dwc[h] = (float)sacc;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone loss_edges / edge_error on logits [rows][2] (for callers that hold predictions already;
+// inside the model both are fused into k_head_fwd).  loss_edges: src/gcn/models/model_utils.py:51-78,
+// edge_error: :255-308.  One thread per row, per-workgroup partial sums (fixed order), integer counters.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GCN_BLOCK) void k_loss_edges_fwd(size_t rows, int VVC, int C, const float* __restrict__ logits,
+                                                             const long long* __restrict__ y_edges,
+                                                             const float* __restrict__ edge_cw,
+                                                             float* __restrict__ loss_partial /* [nblocks][2], nullable */,
+                                                             int* __restrict__ counts /* [2][B*C], nullable */, int BC) {
+    __shared__ double lds[GCN_BLOCK * 2];
+    double a = 0, w = 0;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
+        const float l0 = logits[r * 2], l1 = logits[r * 2 + 1];
+        const int y = (int)y_edges[r];
+        if (loss_partial != nullptr) {
+            const float mx = fmaxf(l0, l1);
+            const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+            const float cw = y ? cw1 : cw0;
+            a += (double)(-cw * ((y ? l1 : l0) - lse));
+            w += (double)cw;
+        }
+        if (counts != nullptr) {
+            const int pred = l1 > l0 ? 1 : 0;
+            if (y + pred > 0) {
+                const int b = (int)(r / VVC), c = (int)(r % C);
+                atomicAdd(&counts[BC + b * C + c], 1);
+                if (pred == y) atomicAdd(&counts[b * C + c], 1);
+            }
+        }
+    }
+    if (loss_partial == nullptr) return;
+    lds[threadIdx.x * 2] = a; lds[threadIdx.x * 2 + 1] = w;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2]; lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss_partial[(size_t)blockIdx.x * 2] = (float)lds[0]; loss_partial[(size_t)blockIdx.x * 2 + 1] = (float)lds[1]; }
+}
+
+// dlogits[row][v] = dloss * w[y] * (softmax_v - [v == y]) / sum_w
+__global__ void k_loss_edges_bwd(size_t rows, const float* __restrict__ logits, const long long* __restrict__ y_edges,
+                                 const float* __restrict__ edge_cw, const float* __restrict__ loss_out,
+                                 const float* __restrict__ dloss, float* __restrict__ dlogits) {
+    const float gl = (dloss ? dloss[0] : 1.f) / loss_out[1];
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
+        const float l0 = logits[r * 2], l1 = logits[r * 2 + 1];
+        const int y = (int)y_edges[r];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float inv = 1.f / (e0 + e1);
+        const float w = (y ? edge_cw[1] : edge_cw[0]) * gl;
+        dlogits[r * 2] = w * (e0 * inv - (y == 0 ? 1.f : 0.f));
+        dlogits[r * 2 + 1] = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
+    }
+}

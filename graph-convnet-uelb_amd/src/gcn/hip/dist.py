@@ -1,0 +1,47 @@
+"""Data-parallel helpers: one process per GPU, the batch of graph instances is sharded over ranks, the
+flat gradient buffer is averaged with ONE all-reduce per step (RCCL over xGMI with backend "nccl";
+"gloo" on CPU for tests).  BatchNorm statistics stay per replica, which is what the reference's
+``nn.DataParallel`` does (``src/gcn/train/trainer.py:54``)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_bounds(n, rank_, world_):
+    """Contiguous shard [lo, hi) of n items for rank_ of world_ (sizes differ by at most one)."""
+    base, rem = divmod(n, world_)
+    lo = rank_ * base + min(rank_, rem)
+    return lo, lo + base + (1 if rank_ < rem else 0)
+
+
+def shard_batch(batch, rank_=None, world_=None):
+    """Slice every array of a batch dict along dim 0; 'edge_cw' (global class weights) is left whole."""
+    rank_ = rank() if rank_ is None else rank_
+    world_ = world() if world_ is None else world_
+    n = len(batch["edges_capacity"])
+    lo, hi = shard_bounds(n, rank_, world_)
+    return {k: (v if k == "edge_cw" else v[lo:hi]) for k, v in batch.items()}
+
+
+def broadcast_parameters(params, src=0):
+    if world() > 1:
+        for p in params:
+            dist.broadcast(p.data, src=src)
+
+
+def allreduce_mean_(flat, group=None):
+    """In-place mean over ranks of a flat tensor (the whole gradient in one message)."""
+    w = world()
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / w)
+    return flat

@@ -69,9 +69,14 @@ def _declare(lib):
     lib.gcn_model_bwd.argtypes = [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), c_void_p, c_size_t, c_void_p]
-    if hasattr(lib, "gcn_edge_error"):
-        lib.gcn_edge_error.restype = c_int
-        lib.gcn_edge_error.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_loss_ws_bytes.restype = c_size_t
+    lib.gcn_loss_ws_bytes.argtypes = [c_int, c_int, c_int]
+    lib.gcn_loss_edges_fwd.restype = c_int
+    lib.gcn_loss_edges_fwd.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]
+    lib.gcn_loss_edges_bwd.restype = c_int
+    lib.gcn_loss_edges_bwd.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]
     if hasattr(lib, "gcn_beam_search"):
         lib.gcn_beam_search.restype = c_int
         lib.gcn_beam_search.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -85,7 +90,7 @@ def _declare(lib):
     if hasattr(lib, "gcn_load_factor"):
         lib.gcn_load_factor.restype = c_int
         lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p]
+                                        c_void_p, c_void_p, c_void_p, c_void_p]
 
 
 def load():

@@ -116,6 +116,19 @@ int gcn_model_bwd(const gcn_model_desc* d, const float* cap, const float* demand
                   void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stand-alone loss and edge-error metric on existing two-class logits [B,V,V,C,2].
+ * Replaces loss_edges (src/gcn/models/model_utils.py:51-78) and edge_error / _edge_error (:255-308)
+ * for callers that already hold predictions; inside gcn_model_fwd both are fused into the head.
+ * loss_out[4] = {loss, sum of class weights, edge error %, 0}; err_flags uint8 [B*C].
+ * edge_cw == NULL in gcn_loss_edges_fwd computes the edge error only (loss_out[0] is then NaN).
+ * ---------------------------------------------------------------------------------------------- */
+size_t gcn_loss_ws_bytes(int B, int V, int C);
+int gcn_loss_edges_fwd(int B, int V, int C, const float* logits, const long long* y_edges, const float* edge_cw,
+                       float* loss_out, unsigned char* err_flags, void* ws, size_t ws_bytes, void* stream);
+int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long* y_edges, const float* edge_cw,
+                       const float* loss_out, const float* dloss, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Capacity-aware beam search, batched on the GPU.
  * Replaces BeamSearchAlgorithm.search / _search_single_batch / _beam_search_for_commodity of the
  * four algorithms in src/gcn/algorithms/beamsearch_uelb.py (:37-55, :89-177, :187-274, :289-377,
@@ -140,6 +153,17 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
  * five_d == 0: in = scores [B,V,V,C],   y = log_softmax(in, dim 2) (over the next node j).
  * Exact zeros become -1e-20 (beamsearch_uelb.py:21). */
 int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Maximum load factor per graph of decoded paths (the step right after the beam search).
+ * Replaces mean_feasible_load_factor (src/common/graph/graph_utils.py:90-192) up to its final mean over
+ * the batch, and the per-commodity "path reaches its destination" test of
+ * Evaluator._compute_completion_and_approx (src/gcn/train/evaluator.py:45-52).
+ * paths / path_len as produced by gcn_beam_search (PL columns).  usage_ws: B*V*V int32 scratch.
+ * max_lf float [B] (+inf if a zero-capacity edge is used); complete uint8 [B*C].
+ * ---------------------------------------------------------------------------------------------- */
+int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
+                    const long long* comm, int* usage_ws, float* max_lf, unsigned char* complete, void* stream);
 
 #ifdef __cplusplus
 }
