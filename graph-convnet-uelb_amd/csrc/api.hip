@@ -13,6 +13,7 @@
 #include "beam.hpp"
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
+#include "kernels_strip.hpp"
 
 namespace {
 
@@ -93,6 +94,10 @@ int check_dims(int B, int V, int C, int H) {
 inline int wave_blocks(size_t units, int cap = 512) {
     return (int)std::max<size_t>(1, std::min<size_t>((units + GCN_WAVES_PER_BLOCK - 1) / GCN_WAVES_PER_BLOCK, (size_t)cap));
 }
+// persistent grid of the edge kernels: 256 compute units x 3 resident workgroups
+constexpr int kEdgeGrid = 768;
+// grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
+inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
 inline int elem_blocks(size_t n4) { return (int)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, 4096)); }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -132,7 +137,7 @@ struct LayerFwdWs {
 };
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
-    w.nblk = wave_blocks(d.Rn);
+    w.nblk = strip_blocks(d.Rn, kEdgeGrid);
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
     w.partial = b.f((size_t)w.nblk * 4 * d.H);
@@ -144,7 +149,7 @@ int tn_slices(size_t rows) {
     return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
 }
 
-constexpr int kMaxPartBlocks = 512;    // wave_blocks() cap: rows of the BatchNorm-backward partial buffers
+constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
 
 struct LayerBwdWs {
     float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
@@ -214,9 +219,9 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.W[1] = P[2]; a.bias[1] = P[3]; a.y[1] = S.Vn;
         a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
         a.rng = rng;
-        GCN_PROF_PRE("k_node_fwd2");
-        k_node_fwd2<MT><<<dim3(wave_blocks((d.Rn + 15) / 16), 3, 1), GCN_BLOCK, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_node_fwd2");
+        GCN_PROF_PRE("k_node_fwd3");
+        k_node_fwd3<MT><<<strip_blocks((d.Rn + 15) / 16), 64 * MT, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_node_fwd3");
     }
     {
         EdgeFwdArgs a = {};
@@ -224,9 +229,12 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.src = make_edge_src(pv, e_in, e_in_out, H, p, training);
         a.WU = P[4]; a.bU = P[5]; a.Ve = W.Ve; a.Vn = S.Vn; a.Ux = W.Ux;
         a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
-        GCN_PROF_PRE("k_edge_fwd2");
-        k_edge_fwd2<MT><<<W.nblk, GCN_BLOCK, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_edge_fwd2");
+        GCN_PROF_PRE("k_edge_fwd3");
+        const bool one = d.V <= 16;
+        if (a.src.mode == 0) { if (one) k_edge_fwd3<MT, 0, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 0, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
+        else if (a.src.mode == 1) { if (one) k_edge_fwd3<MT, 1, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 1, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
+        else { if (one) k_edge_fwd3<MT, 2, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 2, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
+        GCN_CHECK_LAUNCH("k_edge_fwd3");
     }
     GCN_PROF_PRE("k_bn_stats_finalize");
     k_bn_stats_finalize<<<2 * (H / 4), GCN_BLOCK, 0, st>>>(W.partial, W.nblk, H, (double)d.Re, (double)d.Rn, S.stats);
@@ -291,10 +299,10 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
             a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
         }
         const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-        const int blocks = wave_blocks(units);
-        GCN_PROF_PRE("k_edge_bwd_main2");
-        k_edge_bwd_main2<MT><<<blocks, GCN_BLOCK, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_edge_bwd_main2");
+        const int blocks = strip_blocks(units, kEdgeGrid);
+        GCN_PROF_PRE("k_edge_bwd3");
+        k_edge_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_edge_bwd3");
         if (nx.on) npart_e = blocks;
     }
     {
@@ -309,10 +317,10 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
             a.next.tmp = nx.x_tmp; a.next.mean = nx.stats + 2 * H; a.next.rstd = nx.stats + 3 * H; a.next.gamma = nx.gamma_x;
             a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
         }
-        const int blocks = wave_blocks((d.Rn + 15) / 16);
-        GCN_PROF_PRE("k_node_bwd2");
-        k_node_bwd2<MT><<<blocks, GCN_BLOCK, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_node_bwd2");
+        const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+        GCN_PROF_PRE("k_node_bwd3");
+        k_node_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
+        GCN_CHECK_LAUNCH("k_node_bwd3");
         if (nx.on) npart_x = blocks;
     }
     const int slab = H * H + H;
@@ -320,7 +328,7 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
         TnProblems pr = {};
         pr.X[0] = W.det; pr.Y[0] = e_in;
         GCN_PROF_PRE("k_gemm_tn(edges)");
-        k_gemm_tn<MT><<<dim3(W.S_e, (MT + 3) / 4, 1), GCN_BLOCK, 0, st>>>(d.Re, H, 1, pr, W.tn_e);
+        k_gemm_tn2<MT><<<dim3(W.S_e, 1, 1), 64 * MT, 0, st>>>(d.Re, H, 1, pr, W.tn_e);
         GCN_CHECK_LAUNCH("k_gemm_tn(edges)");
     }
     {
@@ -329,7 +337,7 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
         pr.X[1] = W.dVn; pr.Y[1] = x_in;     // node_feat.V
         pr.X[2] = W.dVe; pr.Y[2] = x_in;     // edge_feat.V
         GCN_PROF_PRE("k_gemm_tn(nodes)");
-        k_gemm_tn<MT><<<dim3(W.S_n, (MT + 3) / 4, 3), GCN_BLOCK, 0, st>>>(d.Rn, H, 3, pr, W.tn_n);
+        k_gemm_tn2<MT><<<dim3(W.S_n, 1, 3), 64 * MT, 0, st>>>(d.Rn, H, 3, pr, W.tn_n);
         GCN_CHECK_LAUNCH("k_gemm_tn(nodes)");
     }
     {
@@ -725,7 +733,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             pr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
         }
         GCN_PROF_PRE("k_gemm_tn(head)");
-        DISPATCH_MT(d.MT, (k_gemm_tn<MT><<<dim3(W.S_h, (MT + 3) / 4, p.NHID), GCN_BLOCK, 0, st>>>(d.Re, H, p.NHID, pr, W.tn_h)));
+        DISPATCH_MT(d.MT, (k_gemm_tn2<MT><<<dim3(W.S_h, 1, p.NHID), 64 * MT, 0, st>>>(d.Re, H, p.NHID, pr, W.tn_h)));
         GCN_CHECK_LAUNCH("k_gemm_tn(head)");
     }
     {

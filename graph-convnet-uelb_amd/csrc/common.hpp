@@ -143,10 +143,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 // One key per (seed, step, stream id); rng points at two 64-bit words {seed, step} in device memory
-// so that a captured HIP graph sees a new step on every replay.
+// so that a captured HIP graph sees a new step on every replay.  Element (row, col) is kept iff the
+// 16-bit field (col & 1) of hash(row, col >> 1) is >= p * 2^16: one hash serves two neighbouring columns.
 struct DropCfg {
     uint32_t key;
-    uint32_t thresh;   // keep iff (hash >> 8) >= thresh, thresh = p * 2^24
+    uint32_t thresh;   // keep iff field >= thresh, thresh = p * 2^16
     float scale;       // 1 / (1 - p)
     int on;
 };
@@ -161,16 +162,33 @@ __device__ __forceinline__ DropCfg drop_cfg(const unsigned long long* __restrict
         k = mix32(k ^ (uint32_t)step);
         k = mix32(k ^ (uint32_t)(step >> 32) ^ ((uint32_t)stream_id * 0x85EBCA6BU));
         d.key = k;
-        d.thresh = (p >= 1.f) ? 0x1000000U : (uint32_t)(p * 16777216.0f);
+        d.thresh = (p >= 1.f) ? 0x10000U : (uint32_t)(p * 65536.0f);
         d.scale = (p >= 1.f) ? 0.f : 1.0f / (1.0f - p);
     }
     return d;
 }
 __device__ __forceinline__ uint32_t drop_rowhash(const DropCfg& d, uint32_t row) { return mix32(row ^ d.key); }
+// rowhash is already a full avalanche of (row, key); one more multiply round decorrelates the column pairs
+__device__ __forceinline__ uint32_t drop_pairhash(uint32_t rowhash, int colpair) {
+    uint32_t x = rowhash + (uint32_t)colpair * 0x9E3779B9U;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
+    return x;
+}
 // multiplier applied to element (row, col): 0 if dropped, 1/(1-p) if kept
 __device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t rowhash, int col) {
-    const uint32_t h = mix32(rowhash + (uint32_t)col * 0x9E3779B9U);
-    return ((h >> 8) >= d.thresh) ? d.scale : 0.f;
+    const uint32_t h = drop_pairhash(rowhash, col >> 1);
+    const uint32_t f = (col & 1) ? (h >> 16) : (h & 0xFFFFU);
+    return (f >= d.thresh) ? d.scale : 0.f;
+}
+// multipliers of the four columns 4g .. 4g+3 (two hashes)
+__device__ __forceinline__ f32x4 drop_mul4(const DropCfg& d, uint32_t rowhash, int g) {
+    const uint32_t h0 = drop_pairhash(rowhash, 2 * g), h1 = drop_pairhash(rowhash, 2 * g + 1);
+    f32x4 m;
+    m[0] = ((h0 & 0xFFFFU) >= d.thresh) ? d.scale : 0.f;
+    m[1] = ((h0 >> 16) >= d.thresh) ? d.scale : 0.f;
+    m[2] = ((h1 & 0xFFFFU) >= d.thresh) ? d.scale : 0.f;
+    m[3] = ((h1 >> 16) >= d.thresh) ? d.scale : 0.f;
+    return m;
 }
 
 // Per-channel BatchNorm constants for the lane's columns.

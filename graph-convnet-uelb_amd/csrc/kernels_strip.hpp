@@ -1,0 +1,640 @@
+// "Strip" kernels: one workgroup per 16-row tile, one wavefront per 16-column block.
+//
+// Phase A (all threads, elementwise, coalesced): thread (arow, ag) owns the float4 at row arow, columns
+//   4*ag .. 4*ag+3 of the tile; it forms the tile (fused BatchNorm apply / backward elementwise math),
+//   writes whatever must go to HBM as whole rows, and drops the GEMM operand into an LDS tile.
+// Phase B (per wavefront w): reads the whole 16 x H operand tile from LDS in MFMA B-operand order, multiplies by
+//   the 16 weight rows of output column block w held in registers (MT float4 = 16 MFMAs for H = 64) and
+//   finishes the 4 output values per lane.
+// Small register footprint (high occupancy) and short per-wavefront dependency chains: the shapes of
+// this workload (tens of thousands of rows, H = 64) are latency bound, not bandwidth bound.
+// LDS tiles are double buffered, one barrier per tile.
+#pragma once
+#include "common.hpp"
+#include "kernels_fused.hpp"
+#include "kernels_bwd.hpp"
+
+template <int MT>
+struct StripGeom {
+    static constexpr int HP = 16 * MT;
+    static constexpr int LS = HP + 4;          // LDS row stride (floats) of operand tiles
+    static constexpr int NT = 64 * MT;         // threads per workgroup
+    static constexpr int G = 4 * MT;           // float4 column groups per row
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* __restrict__ p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Buffer addressing: a 128-bit descriptor (base, byte count) built from workgroup-uniform values plus a
+// 32-bit per-lane byte offset.  The hardware range-checks the offset: loads beyond the byte count return
+// 0 and stores are dropped, so ragged tiles need neither clamped addresses nor predicated (branched-around)
+// memory instructions, and every memory instruction in a loop body is issued unconditionally.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;        // an offset beyond any descriptor used here (all are < 2 GiB)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float bld1(rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
+// out[16w + 4q + r] for row rs = sum_k tile[rs][k] * Wrow[16w + ..][k]; two accumulation chains hide the
+// 40-cycle dependent latency of v_mfma_f32_16x16x4_f32.
+template <int MT>
+__device__ __forceinline__ f32x4 strip_gemm(const float (*tile)[StripGeom<MT>::LS], const f32x4 (&wf)[MT], int rs, int q) {
+    f32x4 acc0 = f4zero(), acc1 = f4zero();
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+        const f32x4 in = *reinterpret_cast<const f32x4*>(&tile[rs][16 * s + 4 * q]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((t & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][t], in[t], acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][t], in[t], acc1, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
+// weight rows 16w + rs of W ([H][H] row-major), columns 16s + 4q ..: the A operand of column block w
+template <int MT>
+__device__ __forceinline__ void strip_wfrag(f32x4 (&wf)[MT], const float* __restrict__ W, int H, int w, int rs, int q) {
+    const rsrc_t r = make_rsrc(W, (uint32_t)H * H * 4);
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+        const int n = 16 * w + rs, k = 16 * s + 4 * q;
+        wf[s] = bld4(r, (n < H && k < H) ? (uint32_t)(n * H + k) * 4 : kOob);
+    }
+}
+
+// Sum over the 16 lanes of a row (all 16 lanes receive the sum) of four values at once with DPP-fused adds:
+// four independent chains interleaved, so a result is read by a DPP operand no sooner than three
+// instructions after it is written (the hardware needs two); the leading s_nop covers the producer of the inputs.
+#define GCN_DPP4(CTRL)                                                   \
+    "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ f32x4 red16x4(f32x4 v) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
+    asm volatile("s_nop 1\n\t" GCN_DPP4("row_ror:8") GCN_DPP4("row_ror:4") GCN_DPP4("row_ror:2") GCN_DPP4("row_ror:1")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    return f32x4{a, b, c, d};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge forward of layer l (same math and arguments as k_edge_fwd2; MODE = EdgeSrc::mode).  Persistent
+// workgroups walk steps = ((b, i, c) unit, 16-row j tile).  The loop body is straight-line: loads use
+// clamped (always valid) coordinates and results are masked, so the compiler can keep the loads of step
+// n+1 in flight across the MFMA phase of step n (vector-memory operations retire in issue order: the
+// epilogue operands of step n are requested before the phase-A operands of step n+1).
+// partial layout [gridDim.x][4][H], written by the lanes that own each column.
+// ------------------------------------------------------------------------------------------------
+// ONE_TILE: V <= 16, every step ends its unit (no branch around the unit-end code).
+template <int MT, int MODE, bool ONE_TILE>
+__global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
+    using GM = StripGeom<MT>;
+    __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GM::HP];
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const int H = a.H, V = a.V, C = a.C;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    const bool lead = rs == 0 && bcol_ok;
+    const uint32_t rowb = (uint32_t)C * H * 4;                                   // bytes between rows j and j+1
+    const uint32_t voffA = acol_ok ? (uint32_t)arow * rowb + acol * 4 : kOob;     // phase-A lane offset in a tile
+    const uint32_t voffB = bcol_ok ? (uint32_t)rs * rowb + bcol * 4 : kOob;       // phase-B lane offset in a tile
+    const uint32_t voffN = bcol_ok ? (uint32_t)bcol * 4 : kOob;                   // lane offset in one node row
+    const uint32_t voffL = lead ? (uint32_t)bcol * 4 : kOob;                      // same, leading lanes only
+    const EdgeSrc& S = a.src;
+    edge_src_fill_consts<MT>(cl, S, H);
+    const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && MODE == 1);
+    f32x4 psx1 = f4zero(), psx2 = f4zero();
+    const int units = a.B * V * C;
+    const int njt = ONE_TILE ? 1 : (V + 15) / 16;
+    __syncthreads();
+    // unit u = (b * V + i) * C + c = node row of (b, i, c); bi = b * V + i
+    int u = blockIdx.x, jt = 0, buf = 0;
+    int bi = u / C, c = u - bi * C;
+    f32x4 ra = f4zero(), rb = f4zero();
+    float rcap = 0.f;
+    // element offset of edge row (bi, 16 jt, c) and byte count of the tile's valid rows
+    auto tile_elem = [&](int bi_, int c_, int jt_) { return (((size_t)bi_ * V + jt_ * 16) * C + c_) * (size_t)H; };
+    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + (uint32_t)H * 4; };
+    auto load_raw = [&](int bi_, int c_, int jt_) {
+        const size_t e0 = tile_elem(bi_, c_, jt_);
+        const uint32_t nb = tile_bytes(jt_);
+        if constexpr (MODE == 0) ra = bld4(make_rsrc(S.e_in + e0, nb), voffA);
+        if constexpr (MODE == 1) { ra = bld4(make_rsrc(S.prev_tmp + e0, nb), voffA); rb = bld4(make_rsrc(S.prev_in + e0, nb), voffA); }
+        if constexpr (MODE == 2)
+            rcap = bld1(make_rsrc(S.cap + (size_t)bi_ * V + jt_ * 16, (uint32_t)min(16, V - jt_ * 16) * 4), (uint32_t)arow * 4);
+    };
+    // The first step's phase-A operands are requested before every other prologue load: when the loop
+    // is entered at least as many younger memory operations are outstanding as on the loop's back edge, and
+    // the wait at the top of the loop is the steady-state count rather than "everything".
+    load_raw(bi, c, 0);
+    __builtin_amdgcn_sched_barrier(0);       // keep the instruction scheduler from moving these past the loads below
+    f32x4 wf[MT];
+    strip_wfrag<MT>(wf, a.WU, H, w, rs, q);
+    const f32x4 bu = bld4(make_rsrc(a.bU, H * 4), voffN);
+    f32x4 vei = bld4(make_rsrc(a.Ve + (size_t)u * H, H * 4), voffN);
+    f32x4 uxv = bld4(make_rsrc(a.Ux + (size_t)u * H, H * 4), voffN);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 num = f4zero(), den = f4zero(), s1 = f4zero(), s2 = f4zero();
+    while (true) {
+        const size_t e0 = tile_elem(bi, c, jt);
+        const uint32_t nbytes = tile_bytes(jt);
+        // ---- phase A of the current step
+        {
+            const int j = jt * 16 + arow;
+            const bool valid = j < V && acol_ok;
+            f32x4 val;
+            if constexpr (MODE == 0) val = ra;
+            if constexpr (MODE == 2) val = ld4(&cl[CL_WE][acol]) * rcap;
+            if constexpr (MODE == 1) {
+                const f32x4 pm = ld4(&cl[CL_PMEAN][acol]), pr = ld4(&cl[CL_PRSTD][acol]);
+                const f32x4 pg = ld4(&cl[CL_PGAMMA][acol]), pb = ld4(&cl[CL_PBETA][acol]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float bn = (ra[k] - pm[k]) * pr[k] * pg[k] + pb[k];
+                    val[k] = (bn > 0.f ? bn : 0.f) + rb[k];
+                }
+                if (dc.on) {
+                    const uint32_t erow = (uint32_t)(((size_t)bi * V + j) * C + c);
+                    val *= drop_mul4(dc, drop_rowhash(dc, erow), ag);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[k] = valid ? val[k] : 0.f;
+            if constexpr (MODE != 0) bst4(make_rsrc(S.e_out + e0, nbytes), voffA, val);
+            st4(&tile[buf][arow][acol], val);
+        }
+        // ---- loads, oldest needed first: next unit's node rows, this step's epilogue rows, next step's phase A
+        const int b = bi / V;
+        const bool valid = jt * 16 + rs < V && bcol_ok;
+        int nu = u, njt2 = jt + 1;
+        if (ONE_TILE || njt2 == njt) { njt2 = 0; nu = u + gridDim.x; }
+        const bool more = nu < units;
+        const int nuc = min(nu, units - 1);
+        const int nbi = nuc / C, nc = nuc - nbi * C;
+        const f32x4 vei_n = bld4(make_rsrc(a.Ve + (size_t)nuc * H, H * 4), voffN);
+        const f32x4 uxv_n = bld4(make_rsrc(a.Ux + (size_t)nuc * H, H * 4), voffN);
+        const size_t n0 = ((size_t)(b * V + jt * 16) * C + c) * (size_t)H;       // node row (b, 16 jt, c)
+        const f32x4 vej = bld4(make_rsrc(a.Ve + n0, nbytes), voffB);
+        const f32x4 vnj = bld4(make_rsrc(a.Vn + n0, nbytes), voffB);
+        load_raw(nbi, nc, njt2);
+        __syncthreads();
+        // ---- phase B
+        const f32x4 et = strip_gemm<MT>(tile[buf], wf, rs, q) + (vei + bu) + vej;
+        bst4(make_rsrc(a.e_tmp + e0, nbytes), voffB, et);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = valid ? et[r] : 0.f;
+            const float g = valid ? sigmoidf_(et[r]) : 0.f;
+            num[r] += g * vnj[r];
+            den[r] += g;
+            s1[r] += x;
+            s2[r] += x * x;
+        }
+        buf ^= 1;
+        if (ONE_TILE || nu != u) {
+            // ---- unit end: aggregate over j, node update, statistics
+            num = red16x4(num); den = red16x4(den);
+            f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = num;
+            if (a.mean_agg) {
+                D = den + 1e-20f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) A[r] = num[r] * __builtin_amdgcn_rcpf(D[r]);      // 1 ulp reciprocal
+            }
+            const f32x4 xt = uxv + A;
+            bst4(make_rsrc(a.x_tmp + (size_t)u * H, H * 4), voffL, xt);
+            bst4(make_rsrc(a.Aout + (size_t)u * H, H * 4), voffL, A);
+            bst4(make_rsrc(a.Dout + (size_t)u * H, H * 4), voffL, D);
+            psx1 += xt; psx2 += xt * xt;
+            num = f4zero(); den = f4zero();
+        }
+        if (!more) break;
+        u = nu; jt = njt2; bi = nbi; c = nc; vei = vei_n; uxv = uxv_n;
+    }
+    s1 = red16x4(s1); s2 = red16x4(s2);        // edge statistics: per-lane sums over all steps, reduced once
+    if (lead) {
+        float* p = a.partial + (size_t)blockIdx.x * 4 * H;
+        st4(p + bcol, s1); st4(p + H + bcol, s2); st4(p + 2 * H + bcol, psx1); st4(p + 3 * H + bcol, psx2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node forward of layer l (same math and arguments as k_node_fwd2): one workgroup per 16-row tile;
+// each wavefront produces its column block of all three linears.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void k_node_fwd3(NodeFwdArgs a) {
+    using GM = StripGeom<MT>;
+    __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const int H = a.H;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    f32x4 pm = f4zero(), pr = f4zero(), pg = f4zero(), pb = f4zero();
+    if (a.apply && acol_ok) { pm = ld4(a.pmean + acol); pr = ld4(a.prstd + acol); pg = ld4(a.pgamma + acol); pb = ld4(a.pbeta + acol); }
+    f32x4 wf[3][MT];
+    f32x4 bias[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        strip_wfrag<MT>(wf[k], a.W[k], H, w, rs, q);
+        bias[k] = bcol_ok ? ld4(a.bias[k] + bcol) : f4zero();
+    }
+    const DropCfg dc = drop_cfg(a.rng, a.drop_sid, a.drop_p, a.drop_on && a.apply);
+    const int ntiles = (a.rows + 15) / 16;
+    int buf = 0;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        {
+            const int row = tl * 16 + arow;
+            const bool valid = row < a.rows && acol_ok;
+            f32x4 val = f4zero();
+            if (valid) {
+                if (!a.apply) {
+                    val = ld4(a.x_in + (size_t)row * H + acol);
+                } else {
+                    const f32x4 tp = ld4(a.prev_tmp + (size_t)row * H + acol);
+                    const f32x4 rin = ld4(a.prev_in + (size_t)row * H + acol);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bn = (tp[r] - pm[r]) * pr[r] * pg[r] + pb[r];
+                        val[r] = (bn > 0.f ? bn : 0.f) + rin[r];
+                    }
+                    if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), ag);
+                    if (a.x_out != nullptr) st4(a.x_out + (size_t)row * H + acol, val);
+                }
+            }
+            if (acol < GM::HP) st4(&tile[buf][arow][acol], val);
+        }
+        __syncthreads();
+        const int row = tl * 16 + rs;
+        const bool valid = row < a.rows && bcol_ok;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 o = strip_gemm<MT>(tile[buf], wf[k], rs, q) + bias[k];
+            if (valid) st4(a.y[k] + (size_t)row * H + bcol, o);
+        }
+        buf ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge backward of layer l (same math and arguments as k_edge_bwd_main2).  Persistent workgroups walk
+// steps = ((b, c, i-chunk, j-tile) unit, i of the chunk); straight-line loop body with clamped loads as in
+// k_edge_fwd3.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
+    using GM = StripGeom<MT>;
+    constexpr int HP = GM::HP;
+    __shared__ __attribute__((aligned(16))) float tdet[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float tpre[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float ce[6][HP];     // edges: mean, rstd, gamma, beta, m1, m2
+    __shared__ __attribute__((aligned(16))) float cx[6][HP];     // nodes: same
+    __shared__ __attribute__((aligned(16))) float ncl[4][HP];    // layer l-1 edges: mean, rstd, gamma, beta
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const int H = a.H, V = a.V, C = a.C, IT = a.IT;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    const bool lead = rs == 0 && bcol_ok;
+    const uint32_t rowb = (uint32_t)C * H * 4;                                   // bytes between rows j and j+1
+    const uint32_t voffA = acol_ok ? (uint32_t)arow * rowb + acol * 4 : kOob;     // phase-A lane offset in a tile
+    const uint32_t voffB = bcol_ok ? (uint32_t)rs * rowb + bcol * 4 : kOob;       // phase-B lane offset in a tile
+    const uint32_t voffNA = acol_ok ? (uint32_t)acol * 4 : kOob;                  // phase-A lane offset in one node row
+    const uint32_t voffL = lead ? (uint32_t)bcol * 4 : kOob;                      // leading lanes, one node row
+    const bool do_next = a.next.tmp != nullptr;
+    const bool mean_agg = a.mean_agg != 0;
+    const float* __restrict__ ntmp = do_next ? a.next.tmp : a.e_tmp;     // always a readable edge tensor
+    clds_fill(ce[0], a.stats, H, HP); clds_fill(ce[1], a.stats + H, H, HP);
+    clds_fill(ce[2], a.gamma_e, H, HP); clds_fill(ce[3], a.beta_e, H, HP);
+    clds_fill(ce[4], a.bstats_e, H, HP); clds_fill(ce[5], a.bstats_e + H, H, HP);
+    clds_fill(cx[0], a.stats + 2 * H, H, HP); clds_fill(cx[1], a.stats + 3 * H, H, HP);
+    clds_fill(cx[2], a.gamma_x, H, HP); clds_fill(cx[3], a.beta_x, H, HP);
+    clds_fill(cx[4], a.bstats_x, H, HP); clds_fill(cx[5], a.bstats_x + H, H, HP);
+    clds_fill(ncl[0], do_next ? a.next.mean : nullptr, H, HP); clds_fill(ncl[1], do_next ? a.next.rstd : nullptr, H, HP);
+    clds_fill(ncl[2], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(ncl[3], do_next ? a.next.beta : nullptr, H, HP);
+    const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    f32x4 na1 = f4zero(), na2 = f4zero();
+    const int njt = (V + 15) / 16;
+    const int nit = (V + IT - 1) / IT;
+    const int units = a.B * nit * njt * C;
+    const size_t Rn = (size_t)a.B * V * C;
+    __syncthreads();
+    int u = blockIdx.x, buf = 0;
+    int c, jt, it, b;
+    auto decode = [&](int uu, int& c_, int& jt_, int& it_, int& b_) {
+        int tt = uu;
+        c_ = tt % C; tt /= C;
+        jt_ = tt % njt; tt /= njt;
+        it_ = tt % nit;
+        b_ = tt / nit;
+    };
+    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + (uint32_t)H * 4; };
+    f32x4 r_dn, r_tp, r_dxn, r_xt, r_Dv, r_ai, vnj;
+    auto load_raw = [&](int b_, int c_, int jt_, int i_) {
+        const size_t nrow_i = (size_t)(b_ * V + i_) * C + c_;
+        const size_t e0 = (((size_t)(b_ * V + i_) * V + jt_ * 16) * C + c_) * (size_t)H;
+        const uint32_t nb = tile_bytes(jt_);
+        r_dn = bld4(make_rsrc(a.de + e0, nb), voffA);
+        r_tp = bld4(make_rsrc(a.e_tmp + e0, nb), voffA);
+        r_dxn = bld4(make_rsrc(a.dx + nrow_i * H, H * 4), voffNA);
+        r_xt = bld4(make_rsrc(a.x_tmp + nrow_i * H, H * 4), voffNA);
+        r_Dv = bld4(make_rsrc(a.Dn + nrow_i * H, H * 4), voffNA);
+        r_ai = bld4(make_rsrc(a.Aagg + nrow_i * H, H * 4), voffNA);
+    };
+    auto load_vnj = [&](int b_, int c_, int jt_) {
+        vnj = bld4(make_rsrc(a.Vn + ((size_t)(b_ * V + jt_ * 16) * C + c_) * (size_t)H, tile_bytes(jt_)), voffA);
+    };
+    decode(u, c, jt, it, b);
+    int i = it * IT, i_end = min(V, (it + 1) * IT);
+    // first step's operands before every other prologue load (see k_edge_fwd3)
+    load_raw(b, c, jt, i);
+    load_vnj(b, c, jt);
+    __builtin_amdgcn_sched_barrier(0);       // keep the instruction scheduler from moving these past the loads below
+    f32x4 wf[MT];
+    strip_wfrag<MT>(wf, a.WUt, H, w, rs, q);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 cve = f4zero(), cvn = f4zero();
+    while (true) {
+        const size_t nrow_i = (size_t)(b * V + i) * C + c;
+        const size_t e0 = (((size_t)(b * V + i) * V + jt * 16) * C + c) * (size_t)H;
+        const uint32_t nbytes = tile_bytes(jt);
+        const int ja = jt * 16 + arow;
+        const bool valid_a = ja < V && acol_ok;
+        // ---- phase A
+        {
+            const f32x4 xmu = ld4(&cx[0][acol]), xrs = ld4(&cx[1][acol]), xga = ld4(&cx[2][acol]);
+            const f32x4 xbe = ld4(&cx[3][acol]), xm1 = ld4(&cx[4][acol]), xm2 = ld4(&cx[5][acol]);
+            const f32x4 emu = ld4(&ce[0][acol]), ers = ld4(&ce[1][acol]), ega = ld4(&ce[2][acol]);
+            const f32x4 ebe = ld4(&ce[3][acol]), em1 = ld4(&ce[4][acol]), em2 = ld4(&ce[5][acol]);
+            f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f}, dme = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (dcx.on) {
+                const uint32_t erow = (uint32_t)(((size_t)(b * V + i) * V + ja) * C + c);
+                dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), ag);
+                dme = drop_mul4(dce, drop_rowhash(dce, erow), ag);
+            }
+            f32x4 det, dpre;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // node-side BatchNorm backward of row (b, i, c): qi = dx_tmp / D
+                const float xhx = (r_xt[r] - xmu[r]) * xrs[r];
+                const float bnx = xhx * xga[r] + xbe[r];
+                const float dxd = r_dxn[r] * dmx[r];
+                const float dbnx = bnx > 0.f ? dxd : 0.f;
+                const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
+                const float qi = mean_agg ? dxt * __builtin_amdgcn_rcpf(r_Dv[r]) : dxt;
+                const float aiv = mean_agg ? r_ai[r] : 0.f;
+                const float x = r_tp[r];
+                const float xh = (x - emu[r]) * ers[r];
+                const float bn = xh * ega[r] + ebe[r];
+                const float d = r_dn[r] * dme[r];
+                const float dbn = bn > 0.f ? d : 0.f;
+                const float g = sigmoidf_(x);
+                const float v = ega[r] * ers[r] * (dbn - em1[r] - xh * em2[r]) + qi * (vnj[r] - aiv) * g * (1.f - g);
+                det[r] = valid_a ? v : 0.f;
+                dpre[r] = valid_a ? d : 0.f;
+                cve[r] += det[r];
+                cvn[r] += valid_a ? qi * g : 0.f;
+            }
+            bst4(make_rsrc(a.det_out + e0, nbytes), voffA, det);
+            st4(&tdet[buf][arow][acol], det);
+            st4(&tpre[buf][arow][acol], dpre);
+        }
+        // ---- operand of this step's statistics, then the next step's phase-A operands
+        const bool valid_b = jt * 16 + rs < V && bcol_ok;
+        const f32x4 ntp = bld4(make_rsrc(ntmp + e0, nbytes), voffB);
+        int nu = u, ni = i + 1;
+        if (ni >= i_end) nu = u + gridDim.x;
+        const bool unit_end = nu != u;
+        const bool more = nu < units;
+        int nc = c, njt2 = jt, nit2 = it, nb = b, ni_end = i_end;
+        if (unit_end) {
+            decode(min(nu, units - 1), nc, njt2, nit2, nb);
+            ni = nit2 * IT; ni_end = min(V, (nit2 + 1) * IT);
+        }
+        // column sums of the finished unit (dropped by the range check while the unit continues)
+        {
+            const size_t n0 = ((size_t)it * Rn + (size_t)(b * V + jt * 16) * C + c) * (size_t)H;
+            const uint32_t nbu = unit_end ? nbytes : 0u;
+            bst4(make_rsrc(a.colVe + n0, nbu), voffA, cve);
+            bst4(make_rsrc(a.colVn + n0, nbu), voffA, cvn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cve[r] = unit_end ? 0.f : cve[r]; cvn[r] = unit_end ? 0.f : cvn[r]; }
+        }
+        load_raw(nb, nc, njt2, ni);
+        load_vnj(nb, nc, njt2);
+        __syncthreads();
+        // ---- phase B
+        const f32x4 din = strip_gemm<MT>(tdet[buf], wf, rs, q) + ld4(&tpre[buf][rs][bcol]);
+        f32x4 rsum = ld4(&tdet[buf][rs][bcol]);
+        bst4(make_rsrc(a.de + e0, nbytes), voffB, din);
+        {
+            const f32x4 nmu = ld4(&ncl[0][bcol]), nrs = ld4(&ncl[1][bcol]), nga = ld4(&ncl[2][bcol]), nbe = ld4(&ncl[3][bcol]);
+            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (ndc.on) {
+                const uint32_t erow_b = (uint32_t)(((size_t)(b * V + i) * V + jt * 16 + rs) * C + c);
+                dm = drop_mul4(ndc, drop_rowhash(ndc, erow_b), bcol >> 2);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                const float bn = xh * nga[r] + nbe[r];
+                const float d = (bn > 0.f && valid_b) ? din[r] * dm[r] : 0.f;
+                na1[r] += d;
+                na2[r] += d * xh;
+            }
+        }
+        rsum = red16x4(rsum);      // invalid rows hold zeros in the tile
+        bst4(make_rsrc(a.rowpart + ((size_t)jt * Rn + nrow_i) * H, H * 4), voffL, rsum);
+        buf ^= 1;
+        if (!more) break;
+        u = nu; i = ni; b = nb; c = nc; jt = njt2; it = nit2; i_end = ni_end;
+    }
+    if (do_next) {
+        na1 = red16x4(na1); na2 = red16x4(na2);
+        if (lead) {
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, na1);
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, na2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node backward of layer l (same math and arguments as k_node_bwd2): one workgroup per 16-row tile.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
+    using GM = StripGeom<MT>;
+    __shared__ __attribute__((aligned(16))) float tu[2][16][GM::LS];     // dUx = dx_tmp
+    __shared__ __attribute__((aligned(16))) float tn[2][16][GM::LS];     // dVn
+    __shared__ __attribute__((aligned(16))) float te[2][16][GM::LS];     // dVe
+    __shared__ __attribute__((aligned(16))) float tp[2][16][GM::LS];     // dpre (residual branch)
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const int H = a.H;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    const bool do_next = a.next.tmp != nullptr;
+    f32x4 xmu = f4zero(), xrs = f4zero(), xga = f4zero(), xbe = f4zero(), xm1 = f4zero(), xm2 = f4zero();
+    if (acol_ok) {
+        xmu = ld4(a.mean + acol); xrs = ld4(a.rstd + acol); xga = ld4(a.gamma + acol); xbe = ld4(a.beta + acol);
+        xm1 = ld4(a.bstats + acol); xm2 = ld4(a.bstats + H + acol);
+    }
+    f32x4 wfu[MT], wfn[MT], wfe[MT];
+    strip_wfrag<MT>(wfu, a.WnUt, H, w, rs, q);
+    strip_wfrag<MT>(wfn, a.WnVt, H, w, rs, q);
+    strip_wfrag<MT>(wfe, a.WeVt, H, w, rs, q);
+    f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
+    if (do_next && bcol_ok) { nmu = ld4(a.next.mean + bcol); nrs = ld4(a.next.rstd + bcol); nga = ld4(a.next.gamma + bcol); nbe = ld4(a.next.beta + bcol); }
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    f32x4 na1 = f4zero(), na2 = f4zero();
+    const int ntiles = (a.rows + 15) / 16;
+    int buf = 0;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        {
+            const int row = tl * 16 + arow;
+            const bool valid = row < a.rows && acol_ok;
+            f32x4 dux = f4zero(), dvn = f4zero(), dve = f4zero(), dpre = f4zero();
+            if (valid) {
+                const size_t off = (size_t)row * H + acol;
+                const f32x4 dxo = ld4(a.dx + off);
+                const f32x4 xt = ld4(a.x_tmp + off);
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (dcx.on) dm = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)row), ag);
+                for (int k = 0; k < a.nit; ++k) {
+                    dvn += ld4(a.colVn + (size_t)k * a.rows * H + off);
+                    dve += ld4(a.colVe + (size_t)k * a.rows * H + off);
+                }
+                for (int k = 0; k < a.njt; ++k) dve += ld4(a.rowpart + (size_t)k * a.rows * H + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (xt[r] - xmu[r]) * xrs[r];
+                    const float bn = xh * xga[r] + xbe[r];
+                    const float d = dxo[r] * dm[r];
+                    dpre[r] = d;
+                    const float dbn = bn > 0.f ? d : 0.f;
+                    dux[r] = xga[r] * xrs[r] * (dbn - xm1[r] - xh * xm2[r]);
+                }
+                st4(a.dxtmp_out + off, dux);
+                st4(a.dVn_out + off, dvn);
+                st4(a.dVe_out + off, dve);
+            }
+            if (acol < GM::HP) {
+                st4(&tu[buf][arow][acol], dux); st4(&tn[buf][arow][acol], dvn);
+                st4(&te[buf][arow][acol], dve); st4(&tp[buf][arow][acol], dpre);
+            }
+        }
+        const int row = tl * 16 + rs;
+        const bool valid = row < a.rows && bcol_ok;
+        const f32x4 ntp = (do_next && valid) ? ld4(a.next.tmp + (size_t)row * H + bcol) : f4zero();
+        __syncthreads();
+        f32x4 acc = strip_gemm<MT>(tu[buf], wfu, rs, q);
+        acc += strip_gemm<MT>(tn[buf], wfn, rs, q);
+        acc += strip_gemm<MT>(te[buf], wfe, rs, q);
+        if (bcol < GM::HP) acc += *reinterpret_cast<const f32x4*>(&tp[buf][rs][bcol]);
+        if (valid) {
+            st4(a.dx + (size_t)row * H + bcol, acc);
+            if (do_next) {
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                    const float bn = xh * nga[r] + nbe[r];
+                    const float d = bn > 0.f ? acc[r] * dm[r] : 0.f;
+                    na1[r] += d;
+                    na2[r] += d * xh;
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    if (do_next) {
+        na1 = red16x4(na1); na2 = red16x4(na2);
+        if (rs == 0 && bcol_ok) {
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, na1);
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, na2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM dW[n][k] = sum_row X[row][n] * Y[row][k], db[n] = sum_row X[row][n] (same partial
+// layout as k_gemm_tn: [slice][prob][H*H + H]).  One workgroup per (row slice, problem); per 16-row tile
+// the workgroup stages X and Y rows coalesced into LDS, wavefront w then accumulates the 16 x H block of
+// dW rows 16w.. with MFMA operands read from LDS (A[i = n][kk = row], B[kk = row][j = k]).
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void k_gemm_tn2(size_t rows, int H, int nprob, TnProblems pr, float* __restrict__ partial) {
+    constexpr int HP = 16 * MT, LT = HP + 16, G = 4 * MT;      // row stride 16 mod 32: conflict-free ds_read_b32
+    __shared__ __attribute__((aligned(16))) float tx[2][16][LT];
+    __shared__ __attribute__((aligned(16))) float ty[2][16][LT];
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / G, ag = t - arow * G, acol = 4 * ag;
+    const bool acol_ok = acol < H;
+    const int prob = blockIdx.z, slice = blockIdx.x, nslices = gridDim.x;
+    const float* __restrict__ X = pr.X[prob];
+    const float* __restrict__ Y = pr.Y[prob];
+    const size_t ntiles = (rows + 15) / 16;
+    const size_t per = (ntiles + nslices - 1) / nslices;
+    const size_t t0 = (size_t)slice * per, t1 = min(ntiles, t0 + per);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) acc[k] = f4zero();
+    float bsum = 0.f;
+    f32x4 xv = f4zero(), yv = f4zero();
+    auto fetch = [&](size_t tile) {
+        const size_t row = tile * 16 + arow;
+        const bool valid = row < rows && acol_ok;
+        xv = valid ? ld4(X + row * H + acol) : f4zero();
+        yv = valid ? ld4(Y + row * H + acol) : f4zero();
+    };
+    if (t0 < t1) fetch(t0);
+    int buf = 0;
+    for (size_t tile = t0; tile < t1; ++tile) {
+        if (acol < HP) { st4(&tx[buf][arow][acol], xv); st4(&ty[buf][arow][acol], yv); }
+        if (tile + 1 < t1) fetch(tile + 1);          // next tile's rows are in flight during this tile's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float av = tx[buf][4 * st + q][16 * w + rs];
+            bsum += av;
+#pragma unroll
+            for (int k = 0; k < MT; ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ty[buf][4 * st + q][16 * k + rs], acc[k], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    float* out = partial + ((size_t)slice * nprob + prob) * ((size_t)H * H + H);
+#pragma unroll
+    for (int k = 0; k < MT; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = 16 * w + 4 * q + r, kc = 16 * k + rs;
+            if (nn < H && kc < H) out[(size_t)nn * H + kc] = acc[k][r];
+        }
+    bsum = redq(bsum);
+    const int n = 16 * w + rs;
+    if (q == 0 && n < H) out[(size_t)H * H + n] = bsum;
+}

@@ -14,5 +14,5 @@ for line in out.split('\n'):
         cur[m.group(1).strip()] = m.group(2)
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 for r in rows:
-    if pat in r["name"]:
+    if re.search(pat, r["name"]):
         print("%-64s vgpr=%s agpr=%s scratch=%s occ=%s lds=%s" % (r["name"][:64], r.get("VGPRs"), r.get("AGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS Size")))

@@ -37,6 +37,17 @@ def assert_close(got, ref, what, atol=0.0):
     assert err <= RTOL * scale + atol, f"{what}: max err {err:.3e} vs scale {scale:.3e} (atol {atol:.1e})"
 
 
+def _relu_margin(x, e, P, agg):
+    """Smallest |BatchNorm output| of the layer on this input.  A ReLU input within fp32 rounding (~1e-6 here) of
+    zero may legitimately fall on either side in two correct implementations, which moves the gradients by a
+    whole element; gradient comparisons therefore use inputs whose margin is well above that."""
+    with torch.no_grad():
+        _, _, t = gcn_oracle.gcn_layer(x, e, P, "", agg)
+        be = gcn_oracle.batch_norm_rows(t["e_tmp"], P["bn_edge.batch_norm.weight"], P["bn_edge.batch_norm.bias"])
+        bx = gcn_oracle.batch_norm_rows(t["x_tmp"], P["bn_node.batch_norm.weight"], P["bn_node.batch_norm.bias"])
+    return min(float(be.abs().min()), float(bx.abs().min()))
+
+
 class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
@@ -50,20 +61,25 @@ LAYER_CASES = [(2, 5, 3, 8, "mean"), (2, 6, 4, 12, "mean"), (3, 14, 10, 64, "mea
 def test_layer_forward_backward_matches_oracle(B, V, C, H, agg):
     from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
     dev = _dev()
-    torch.manual_seed(B * 1000 + V * 10 + H)
-    layer = ResidualGatedGCNLayer(H, agg)
-    with torch.no_grad():
-        for n, p in layer.named_parameters():
-            if "batch_norm.weight" in n:
-                p.add_(0.2 * torch.randn_like(p))
-            if "batch_norm.bias" in n:
-                p.add_(0.1 * torch.randn_like(p))
-    layer.eval()                      # dropout off; BatchNorm still uses batch statistics
-    x = torch.randn(B, V, C, H)
-    e = torch.randn(B, V, V, C, H) * 3.0
-    gx = torch.randn(B, V, C, H)
-    ge = torch.randn(B, V, V, C, H)
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    for attempt in range(64):
+        torch.manual_seed(B * 1000 + V * 10 + H + 7919 * attempt)
+        layer = ResidualGatedGCNLayer(H, agg)
+        with torch.no_grad():
+            for n, p in layer.named_parameters():
+                if "batch_norm.weight" in n:
+                    p.add_(0.2 * torch.randn_like(p))
+                if "batch_norm.bias" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+        layer.eval()                      # dropout off; BatchNorm still uses batch statistics
+        x = torch.randn(B, V, C, H)
+        e = torch.randn(B, V, V, C, H) * 3.0
+        gx = torch.randn(B, V, C, H)
+        ge = torch.randn(B, V, V, C, H)
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+        if _relu_margin(x, e, P, agg) > 2e-6:
+            break
+    else:
+        pytest.fail("no tie-free seed found")
     xo, eo = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
     x1, e1, _ = gcn_oracle.gcn_layer(xo, eo, P, "", agg)
     ((x1 * gx).sum() + (e1 * ge).sum()).backward()
@@ -123,13 +139,18 @@ def test_layer_train_mode_dropout_semantics():
     mask), (4) the mask changes from call to call, and eval mode is deterministic."""
     from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
     dev = _dev()
-    torch.manual_seed(0)
     B, V, C, H, p = 3, 14, 4, 64, 0.3
-    layer = ResidualGatedGCNLayer(H, "mean", dropout_rate=p)
-    x = torch.randn(B, V, C, H) + 4.0          # keeps relu(BN)+residual away from 0 so the mask is readable
-    e = torch.randn(B, V, V, C, H) + 4.0
-    gx, ge = torch.randn(B, V, C, H), torch.randn(B, V, V, C, H)
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    for seed in range(64):
+        torch.manual_seed(seed)
+        layer = ResidualGatedGCNLayer(H, "mean", dropout_rate=p)
+        x = torch.randn(B, V, C, H) + 4.0          # keeps relu(BN)+residual away from 0 so the mask is readable
+        e = torch.randn(B, V, V, C, H) + 4.0
+        gx, ge = torch.randn(B, V, C, H), torch.randn(B, V, V, C, H)
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+        if _relu_margin(x, e, P, "mean") > 5e-6:
+            break
+    else:
+        pytest.fail("no tie-free seed found")
     layer = layer.to(dev).train()
     xh, eh = x.to(dev).requires_grad_(True), e.to(dev).requires_grad_(True)
     x1, e1 = layer(xh, eh)
