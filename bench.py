@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "graph-convnet-uelb_amd"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (spec)
-DOMINANT_KERNEL = "k_edge_bwd_main"
+DOMINANT_KERNEL = "k_edge_bwd3"
 
 
 class Cfg(dict):

@@ -266,24 +266,40 @@ struct NextLayer {
     bool on;
     const float *e_tmp, *x_tmp, *stats, *gamma_x, *beta_x, *gamma_e, *beta_e;
     int sid;
+    float* const* G;                // gradient pointers of that layer (its BatchNorm gradients are finished here)
 };
 
+// Reduce jobs that finish a layer's BatchNorm backward: partial [nP][2][H] -> dbeta, dgamma and
+// bstats = (mean(dbn), mean(dbn * xhat)) for the edge (which = 0) or node (1) BatchNorm.
+void bn_finish_job(ReduceJob& j, const float* partial, int nP, int H, double n, float* dbeta, float* dgamma, float* bstats) {
+    j.partial = partial; j.nP = nP; j.ncols = 2 * H;
+    j.rd.n = 2;
+    j.rd.dst[0] = dbeta; j.rd.dst[1] = dgamma;
+    j.rd.dst2[0] = bstats; j.rd.dst2[1] = bstats + H;
+    j.rd.scale2 = 1.0 / n;
+    j.rd.off[0] = 0; j.rd.off[1] = H; j.rd.off[2] = 2 * H;
+}
+
 // Backward of one layer.  On entry bpart_e / bpart_x hold npart_e / npart_x rows of this layer's
-// BatchNorm-backward partial sums; on return they hold those of the layer below if nx.on.
+// BatchNorm-backward partial sums; with fin_first they are reduced here first, otherwise the caller's
+// previous reduce launch has already produced bstats_e / bstats_x and this layer's BatchNorm gradients.
+// On return, if nx.on, the same holds for the layer below (its partial sums come out of this layer's
+// kernels and are reduced by this layer's final reduce launch).
 // wT: transposed node_feat.U, node_feat.V, edge_feat.U, edge_feat.V weights of this layer.
 template <int MT>
 int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
                    const float* x_in, const float* e_in, const float* const* P, const float* const* wT, const LayerSaved& S,
                    float* dx, float* de, float* const* G, const LayerBwdWs& W, int& npart_e, int& npart_x,
-                   const NextLayer& nx, hipStream_t st) {
+                   const NextLayer& nx, bool fin_first, hipStream_t st) {
     const int H = d.H;
-    {
-        BnBwdFin fa = {};
-        fa.partial[0] = W.bpart_e; fa.nP[0] = npart_e; fa.n[0] = (double)d.Re; fa.bstats[0] = W.bstats_e; fa.dgamma[0] = G[10]; fa.dbeta[0] = G[11];
-        fa.partial[1] = W.bpart_x; fa.nP[1] = npart_x; fa.n[1] = (double)d.Rn; fa.bstats[1] = W.bstats_x; fa.dgamma[1] = G[8]; fa.dbeta[1] = G[9];
-        GCN_PROF_PRE("k_bn_bwd_finalize");
-        k_bn_bwd_finalize<<<dim3(H / 4, 2, 1), GCN_BLOCK, 0, st>>>(fa, H);
-        GCN_CHECK_LAUNCH("k_bn_bwd_finalize");
+    if (fin_first) {
+        ReduceJobs jobs = {};
+        jobs.n = 2;
+        bn_finish_job(jobs.job[0], W.bpart_e, npart_e, H, (double)d.Re, G[11], G[10], W.bstats_e);
+        bn_finish_job(jobs.job[1], W.bpart_x, npart_x, H, (double)d.Rn, G[9], G[8], W.bstats_x);
+        GCN_PROF_PRE("k_reduce_slabs(bn)");
+        k_reduce_slabs<<<dim3((2 * H + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+        GCN_CHECK_LAUNCH("k_reduce_slabs(bn)");
     }
     {
         EdgeBwdArgs a = {};
@@ -325,24 +341,23 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
     }
     const int slab = H * H + H;
     {
+        // one launch for the four weight-gradient products of the layer
         TnProblems pr = {};
-        pr.X[0] = W.det; pr.Y[0] = e_in;
-        GCN_PROF_PRE("k_gemm_tn(edges)");
-        k_gemm_tn2<MT><<<dim3(W.S_e, 1, 1), 64 * MT, 0, st>>>(d.Re, H, 1, pr, W.tn_e);
-        GCN_CHECK_LAUNCH("k_gemm_tn(edges)");
-    }
-    {
-        TnProblems pr = {};
-        pr.X[0] = W.dxtmp; pr.Y[0] = x_in;   // node_feat.U
-        pr.X[1] = W.dVn; pr.Y[1] = x_in;     // node_feat.V
-        pr.X[2] = W.dVe; pr.Y[2] = x_in;     // edge_feat.V
-        GCN_PROF_PRE("k_gemm_tn(nodes)");
-        k_gemm_tn2<MT><<<dim3(W.S_n, 1, 3), 64 * MT, 0, st>>>(d.Rn, H, 3, pr, W.tn_n);
-        GCN_CHECK_LAUNCH("k_gemm_tn(nodes)");
+        pr.X[0] = W.det; pr.Y[0] = e_in;     // edge_feat.U
+        pr.X[1] = W.dxtmp; pr.Y[1] = x_in;   // node_feat.U
+        pr.X[2] = W.dVn; pr.Y[2] = x_in;     // node_feat.V
+        pr.X[3] = W.dVe; pr.Y[3] = x_in;     // edge_feat.V
+        pr.rows[0] = d.Re; pr.nslices[0] = W.S_e; pr.out[0] = W.tn_e; pr.out_stride[0] = slab;
+        for (int k = 1; k < 4; ++k) {
+            pr.rows[k] = d.Rn; pr.nslices[k] = W.S_n; pr.out[k] = W.tn_n + (size_t)(k - 1) * slab; pr.out_stride[k] = 3 * (size_t)slab;
+        }
+        GCN_PROF_PRE("k_gemm_tn2(layer)");
+        k_gemm_tn2<MT><<<dim3(std::max(W.S_e, W.S_n), 1, 4), 64 * MT, 0, st>>>(H, pr);
+        GCN_CHECK_LAUNCH("k_gemm_tn2(layer)");
     }
     {
         ReduceJobs jobs = {};
-        jobs.n = 2;
+        jobs.n = nx.on ? 4 : 2;
         jobs.job[0].partial = W.tn_e; jobs.job[0].nP = W.S_e; jobs.job[0].ncols = slab;
         jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[4]; jobs.job[0].rd.dst[1] = G[5];
         jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = H * H; jobs.job[0].rd.off[2] = slab;
@@ -352,8 +367,12 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
         rd.dst[0] = G[0]; rd.dst[1] = G[1]; rd.dst[2] = G[2]; rd.dst[3] = G[3]; rd.dst[4] = G[6]; rd.dst[5] = G[7];
         for (int k = 0; k < 3; ++k) { rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H; }
         rd.off[6] = 3 * slab;
+        if (nx.on) {
+            bn_finish_job(jobs.job[2], W.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.bstats_e);
+            bn_finish_job(jobs.job[3], W.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.bstats_x);
+        }
         GCN_PROF_PRE("k_reduce_slabs(layer)");
-        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
     }
     return 0;
@@ -389,7 +408,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
     int npe = nblk_e, npx = nblk_x;
     NextLayer none = {};
-    return layer_bwd_core<MT>(d, agg, p, training, rng, sid, x_in, e_in, P, wT, S, dx, de, G, W, npe, npx, none, st);
+    return layer_bwd_core<MT>(d, agg, p, training, rng, sid, x_in, e_in, P, wT, S, dx, de, G, W, npe, npx, none, true, st);
 }
 
 #define DISPATCH_MT(MTV, CALL)                                   \
@@ -726,25 +745,34 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                                                                       W.head_blk, st))));
     GCN_CHECK_LAUNCH("k_head_bwd");
     int npart_e = W.head_blk, npart_x = 1;
+    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient and the
+    // BatchNorm-backward sums derived from it are zero
+    if (hipMemsetAsync(W.dx, 0, nh * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
+    if (hipMemsetAsync(W.lw.bpart_x, 0, 2 * (size_t)H * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
     if (p.NHID > 0) {
         TnProblems pr = {};
         for (int k = 0; k < p.NHID; ++k) {
             pr.X[k] = dpre_all + (size_t)k * eh;
             pr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
         }
-        GCN_PROF_PRE("k_gemm_tn(head)");
-        DISPATCH_MT(d.MT, (k_gemm_tn2<MT><<<dim3(W.S_h, 1, p.NHID), 64 * MT, 0, st>>>(d.Re, H, p.NHID, pr, W.tn_h)));
-        GCN_CHECK_LAUNCH("k_gemm_tn(head)");
+        for (int k = 0; k < p.NHID; ++k) {
+            pr.rows[k] = d.Re; pr.nslices[k] = W.S_h; pr.out[k] = W.tn_h + (size_t)k * slab; pr.out_stride[k] = (size_t)p.NHID * slab;
+        }
+        GCN_PROF_PRE("k_gemm_tn2(head)");
+        DISPATCH_MT(d.MT, (k_gemm_tn2<MT><<<dim3(W.S_h, 1, p.NHID), 64 * MT, 0, st>>>(H, pr)));
+        GCN_CHECK_LAUNCH("k_gemm_tn2(head)");
     }
     {
         const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
+        // output-layer gradients, hidden-layer weight gradients and the BatchNorm backward of the top layer
         ReduceJobs jobs = {};
-        jobs.n = p.NHID > 0 ? 2 : 1;
         jobs.job[0].partial = W.wpartial; jobs.job[0].nP = W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
         jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[hbase + 2 * p.NHID]; jobs.job[0].rd.dst[1] = G[hbase + 2 * p.NHID + 1];
         jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = p.voc * H; jobs.job[0].rd.off[2] = p.voc * H + p.voc;
-        int maxcols = wcols;
+        int maxcols = std::max(wcols, 2 * H);
+        jobs.n = 1;
         if (p.NHID > 0) {
+            jobs.n = 2;
             jobs.job[1].partial = W.tn_h; jobs.job[1].nP = W.S_h; jobs.job[1].ncols = p.NHID * slab;
             ReduceDst& rd = jobs.job[1].rd;
             rd.n = 2 * p.NHID;
@@ -755,14 +783,13 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             rd.off[2 * p.NHID] = p.NHID * slab;
             maxcols = std::max(maxcols, p.NHID * slab);
         }
+        float* const* GL = G + 3 + GCN_LAYER_NPARAMS * (p.L - 1);
+        bn_finish_job(jobs.job[jobs.n++], W.lw.bpart_e, npart_e, H, (double)d.Re, GL[11], GL[10], W.lw.bstats_e);
+        bn_finish_job(jobs.job[jobs.n++], W.lw.bpart_x, npart_x, H, (double)d.Rn, GL[9], GL[8], W.lw.bstats_x);
         GCN_PROF_PRE("k_reduce_slabs(head)");
         k_reduce_slabs<<<dim3((maxcols + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
     }
-    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient and the
-    // BatchNorm-backward sums derived from it are zero
-    if (hipMemsetAsync(W.dx, 0, nh * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
-    if (hipMemsetAsync(W.lw.bpart_x, 0, 2 * (size_t)H * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
     for (int l = p.L - 1; l >= 0; --l) {
         const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
         const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
@@ -774,10 +801,11 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             const PrevLayer below = prev_of(p, saved, P, l - 1);
             nx.on = true; nx.e_tmp = below.e_tmp; nx.x_tmp = below.x_tmp; nx.stats = below.stats;
             nx.gamma_x = below.gamma_x; nx.beta_x = below.beta_x; nx.gamma_e = below.gamma_e; nx.beta_e = below.beta_e; nx.sid = l - 1;
+            nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
         }
         int rc = 0;
         DISPATCH_MT(d.MT, rc = layer_bwd_core<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, x_act + (size_t)l * nh,
-                                                  e_act + (size_t)l * eh, LP, wT, S, W.dx, W.de, LG, W.lw, npart_e, npart_x, nx, st));
+                                                  e_act + (size_t)l * eh, LP, wT, S, W.dx, W.de, LG, W.lw, npart_e, npart_x, nx, false, st));
         if (rc) return rc;
     }
     // embeddings

@@ -303,8 +303,14 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_node_bwd(
 // partial layout: [slice][prob][H*H + H].
 // ------------------------------------------------------------------------------------------------
 struct TnProblems {
-    const float* X[3];
-    const float* Y[3];
+    const float* X[4];
+    const float* Y[4];
+    // used by k_gemm_tn2 only: rows, row slices and output of each problem; slice s of problem p writes the
+    // slab out[p] + s * out_stride[p]
+    size_t rows[4];
+    int nslices[4];
+    float* out[4];
+    size_t out_stride[4];
 };
 
 template <int MT>
@@ -380,6 +386,8 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_gemm_tn(size_t rows, int H, int n
 // the result does not depend on scheduling.
 struct ReduceDst {
     float* dst[8];
+    float* dst2[8];      // optional second copy of the same columns, multiplied by scale2 (nullptr = none)
+    double scale2;
     int off[9];
     int n;
 };
@@ -389,7 +397,7 @@ struct ReduceJob {
     ReduceDst rd;
 };
 struct ReduceJobs {
-    ReduceJob job[2];
+    ReduceJob job[4];
     int n;
 };
 // grid = (ceil(max ncols / 16), number of jobs)
@@ -423,7 +431,11 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
         for (int k = 0; k < 4; ++k) {
             const int cc = col + k;
             for (int d = 0; d < J.rd.n; ++d)
-                if (cc >= J.rd.off[d] && cc < J.rd.off[d + 1]) { J.rd.dst[d][cc - J.rd.off[d]] = (float)my[k]; break; }
+                if (cc >= J.rd.off[d] && cc < J.rd.off[d + 1]) {
+                    J.rd.dst[d][cc - J.rd.off[d]] = (float)my[k];
+                    if (J.rd.dst2[d] != nullptr) J.rd.dst2[d][cc - J.rd.off[d]] = (float)(my[k] * J.rd.scale2);
+                    break;
+                }
         }
     }
 }

@@ -586,14 +586,16 @@ __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
 // dW rows 16w.. with MFMA operands read from LDS (A[i = n][kk = row], B[kk = row][j = k]).
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(64 * MT) void k_gemm_tn2(size_t rows, int H, int nprob, TnProblems pr, float* __restrict__ partial) {
+__global__ __launch_bounds__(64 * MT) void k_gemm_tn2(int H, TnProblems pr) {
     constexpr int HP = 16 * MT, LT = HP + 16, G = 4 * MT;      // row stride 16 mod 32: conflict-free ds_read_b32
     __shared__ __attribute__((aligned(16))) float tx[2][16][LT];
     __shared__ __attribute__((aligned(16))) float ty[2][16][LT];
     const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
     const int arow = t / G, ag = t - arow * G, acol = 4 * ag;
     const bool acol_ok = acol < H;
-    const int prob = blockIdx.z, slice = blockIdx.x, nslices = gridDim.x;
+    const int prob = blockIdx.z, slice = blockIdx.x, nslices = pr.nslices[prob];
+    if (slice >= nslices) return;                     // uniform per workgroup
+    const size_t rows = pr.rows[prob];
     const float* __restrict__ X = pr.X[prob];
     const float* __restrict__ Y = pr.Y[prob];
     const size_t ntiles = (rows + 15) / 16;
@@ -613,7 +615,8 @@ __global__ __launch_bounds__(64 * MT) void k_gemm_tn2(size_t rows, int H, int np
     if (t0 < t1) fetch(t0);
     int buf = 0;
     for (size_t tile = t0; tile < t1; ++tile) {
-        if (acol < HP) { st4(&tx[buf][arow][acol], xv); st4(&ty[buf][arow][acol], yv); }
+        st4(&tx[buf][arow][acol], xv);
+        st4(&ty[buf][arow][acol], yv);
         if (tile + 1 < t1) fetch(tile + 1);          // next tile's rows are in flight during this tile's MFMAs
         __syncthreads();
 #pragma unroll
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(64 * MT) void k_gemm_tn2(size_t rows, int H, int np
         }
         buf ^= 1;
     }
-    float* out = partial + ((size_t)slice * nprob + prob) * ((size_t)H * H + H);
+    float* out = pr.out[prob] + (size_t)slice * pr.out_stride[prob];
 #pragma unroll
     for (int k = 0; k < MT; ++k)
 #pragma unroll
