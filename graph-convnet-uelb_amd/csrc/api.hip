@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -77,6 +78,7 @@ Dims make_dims(int B, int V, int C, int H) {
     // enough (b, c, i-chunk, j-tile) units to give every SIMD of the chip a wavefront
     const long long fine = (long long)B * C * d.njt * V;
     d.IT = (int)std::max<long long>(1, std::min<long long>(V, fine / 1024));
+    if (const char* e = getenv("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
     d.MT = (H + 15) / 16;
     return d;
@@ -98,6 +100,11 @@ inline int wave_blocks(size_t units, int cap = 512) {
 constexpr int kEdgeGrid = 768;
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
+// grid of a kernel whose workgroups each take a contiguous range of units: no workgroup is left without work
+inline int range_blocks(size_t units, int cap) {
+    const size_t per = (units + cap - 1) / cap;
+    return (int)std::max<size_t>(1, (units + per - 1) / std::max<size_t>(per, 1));
+}
 inline int elem_blocks(size_t n4) { return (int)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, 4096)); }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -137,7 +144,8 @@ struct LayerFwdWs {
 };
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
-    w.nblk = strip_blocks(d.Rn, kEdgeGrid);
+    w.nblk = range_blocks(d.Rn, kEdgeGrid);
+    if (const char* e = getenv("GCN_TUNE_GRID_F")) w.nblk = range_blocks(d.Rn, std::min(atoi(e), 2048));
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
     w.partial = b.f((size_t)w.nblk * 4 * d.H);
@@ -229,6 +237,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.src = make_edge_src(pv, e_in, e_in_out, H, p, training);
         a.WU = P[4]; a.bU = P[5]; a.Ve = W.Ve; a.Vn = S.Vn; a.Ux = W.Ux;
         a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
+        if (const char* e = getenv("GCN_TUNE_PROBE")) a.probe = atoi(e);
         GCN_PROF_PRE("k_edge_fwd3");
         const bool one = d.V <= 16;
         if (a.src.mode == 0) { if (one) k_edge_fwd3<MT, 0, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 0, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
@@ -315,7 +324,8 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
             a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
         }
         const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-        const int blocks = strip_blocks(units, kEdgeGrid);
+        int blocks = strip_blocks(units, kEdgeGrid);
+        if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = strip_blocks(units, std::min(atoi(e), 2048));
         GCN_PROF_PRE("k_edge_bwd3");
         k_edge_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
         GCN_CHECK_LAUNCH("k_edge_bwd3");

@@ -92,6 +92,7 @@ struct EdgeFwdArgs {
     const float* Ve; const float* Vn; const float* Ux;
     float* e_tmp; float* x_tmp; float* Aout; float* Dout; float* partial;
     const unsigned long long* rng;
+    int probe;      // timing probes only: bit k drops one stream of memory traffic (results are then wrong)
 };
 
 template <int MT>

@@ -123,21 +123,33 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
     const int units = a.B * V * C;
     const int njt = ONE_TILE ? 1 : (V + 15) / 16;
     __syncthreads();
-    // unit u = (b * V + i) * C + c = node row of (b, i, c); bi = b * V + i
-    int u = blockIdx.x, jt = 0, buf = 0;
-    int bi = u / C, c = u - bi * C;
+    // Each workgroup walks a contiguous range of units u = (b * V + i) * C + c (= node row of (b, i, c)):
+    // the coordinates advance by counters, and row indices are 32-bit with one widening multiply by the row bytes.
+    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    if (u0 >= u1) {                                    // uniform: no units for this workgroup
+        if (lead) {
+            float* p = a.partial + (size_t)blockIdx.x * 4 * H;
+            st4(p + bcol, psx1); st4(p + H + bcol, psx1); st4(p + 2 * H + bcol, psx1); st4(p + 3 * H + bcol, psx1);
+        }
+        return;
+    }
+    const uint32_t hb = (uint32_t)H * 4;               // bytes of one row
+    auto rowp = [&](const float* base, uint32_t row) { return (const float*)((const char*)base + (uint64_t)row * hb); };
+    auto rowpw = [&](float* base, uint32_t row) { return (float*)((char*)base + (uint64_t)row * hb); };
+    int u = u0, jt = 0, buf = 0;
+    int bi = u / C, c = u - bi * C;                    // bi = b * V + i
+    int b = bi / V, i = bi - b * V;
     f32x4 ra = f4zero(), rb = f4zero();
     float rcap = 0.f;
-    // element offset of edge row (bi, 16 jt, c) and byte count of the tile's valid rows
-    auto tile_elem = [&](int bi_, int c_, int jt_) { return (((size_t)bi_ * V + jt_ * 16) * C + c_) * (size_t)H; };
-    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + (uint32_t)H * 4; };
+    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + hb; };
     auto load_raw = [&](int bi_, int c_, int jt_) {
-        const size_t e0 = tile_elem(bi_, c_, jt_);
-        const uint32_t nb = tile_bytes(jt_);
-        if constexpr (MODE == 0) ra = bld4(make_rsrc(S.e_in + e0, nb), voffA);
-        if constexpr (MODE == 1) { ra = bld4(make_rsrc(S.prev_tmp + e0, nb), voffA); rb = bld4(make_rsrc(S.prev_in + e0, nb), voffA); }
+        const uint32_t erow0 = (uint32_t)(bi_ * V + jt_ * 16) * C + c_;
+        const uint32_t nb = (a.probe & 1) ? 0u : tile_bytes(jt_);
+        if constexpr (MODE == 0) ra = bld4(make_rsrc(rowp(S.e_in, erow0), nb), voffA);
+        if constexpr (MODE == 1) { ra = bld4(make_rsrc(rowp(S.prev_tmp, erow0), nb), voffA); rb = bld4(make_rsrc(rowp(S.prev_in, erow0), nb), voffA); }
         if constexpr (MODE == 2)
-            rcap = bld1(make_rsrc(S.cap + (size_t)bi_ * V + jt_ * 16, (uint32_t)min(16, V - jt_ * 16) * 4), (uint32_t)arow * 4);
+            rcap = bld1(make_rsrc(S.cap + (uint32_t)(bi_ * V + jt_ * 16), (uint32_t)min(16, V - jt_ * 16) * 4), (uint32_t)arow * 4);
     };
     // The first step's phase-A operands are requested before every other prologue load: when the loop
     // is entered at least as many younger memory operations are outstanding as on the loop's back edge, and
@@ -146,13 +158,13 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);       // keep the instruction scheduler from moving these past the loads below
     f32x4 wf[MT];
     strip_wfrag<MT>(wf, a.WU, H, w, rs, q);
-    const f32x4 bu = bld4(make_rsrc(a.bU, H * 4), voffN);
-    f32x4 vei = bld4(make_rsrc(a.Ve + (size_t)u * H, H * 4), voffN);
-    f32x4 uxv = bld4(make_rsrc(a.Ux + (size_t)u * H, H * 4), voffN);
+    const f32x4 bu = bld4(make_rsrc(a.bU, hb), voffN);
+    f32x4 vei = bld4(make_rsrc(rowp(a.Ve, u), hb), voffN);
+    f32x4 uxv = bld4(make_rsrc(rowp(a.Ux, u), hb), voffN);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 num = f4zero(), den = f4zero(), s1 = f4zero(), s2 = f4zero();
     while (true) {
-        const size_t e0 = tile_elem(bi, c, jt);
+        const uint32_t erow0 = (uint32_t)(bi * V + jt * 16) * C + c;
         const uint32_t nbytes = tile_bytes(jt);
         // ---- phase A of the current step
         {
@@ -169,34 +181,34 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
                     const float bn = (ra[k] - pm[k]) * pr[k] * pg[k] + pb[k];
                     val[k] = (bn > 0.f ? bn : 0.f) + rb[k];
                 }
-                if (dc.on) {
-                    const uint32_t erow = (uint32_t)(((size_t)bi * V + j) * C + c);
-                    val *= drop_mul4(dc, drop_rowhash(dc, erow), ag);
-                }
+                if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, erow0 + (uint32_t)arow * C), ag);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) val[k] = valid ? val[k] : 0.f;
-            if constexpr (MODE != 0) bst4(make_rsrc(S.e_out + e0, nbytes), voffA, val);
+            if constexpr (MODE != 0) bst4(make_rsrc(rowpw(S.e_out, erow0), (a.probe & 2) ? 0u : nbytes), voffA, val);
             st4(&tile[buf][arow][acol], val);
         }
+        // ---- next step's coordinates
+        const bool unit_end = ONE_TILE || jt + 1 == njt;
+        int nu = u, njt2 = jt + 1, nbi = bi, nc = c, nb = b, ni = i;
+        if (unit_end) {
+            njt2 = 0; nu = u + 1; nc = c + 1;
+            if (nc == C) { nc = 0; nbi = bi + 1; ni = i + 1; if (ni == V) { ni = 0; nb = b + 1; } }
+        }
+        const bool more = nu < u1;
+        if (!more) { nu = u; njt2 = jt; nbi = bi; nc = c; nb = b; ni = i; }     // last step: reload something valid
         // ---- loads, oldest needed first: next unit's node rows, this step's epilogue rows, next step's phase A
-        const int b = bi / V;
         const bool valid = jt * 16 + rs < V && bcol_ok;
-        int nu = u, njt2 = jt + 1;
-        if (ONE_TILE || njt2 == njt) { njt2 = 0; nu = u + gridDim.x; }
-        const bool more = nu < units;
-        const int nuc = min(nu, units - 1);
-        const int nbi = nuc / C, nc = nuc - nbi * C;
-        const f32x4 vei_n = bld4(make_rsrc(a.Ve + (size_t)nuc * H, H * 4), voffN);
-        const f32x4 uxv_n = bld4(make_rsrc(a.Ux + (size_t)nuc * H, H * 4), voffN);
-        const size_t n0 = ((size_t)(b * V + jt * 16) * C + c) * (size_t)H;       // node row (b, 16 jt, c)
-        const f32x4 vej = bld4(make_rsrc(a.Ve + n0, nbytes), voffB);
-        const f32x4 vnj = bld4(make_rsrc(a.Vn + n0, nbytes), voffB);
+        const f32x4 vei_n = bld4(make_rsrc(rowp(a.Ve, nu), hb), voffN);
+        const f32x4 uxv_n = bld4(make_rsrc(rowp(a.Ux, nu), hb), voffN);
+        const uint32_t n0 = (uint32_t)(b * V + jt * 16) * C + c;                 // node row (b, 16 jt, c)
+        const f32x4 vej = bld4(make_rsrc(rowp(a.Ve, n0), (a.probe & 8) ? 0u : nbytes), voffB);
+        const f32x4 vnj = bld4(make_rsrc(rowp(a.Vn, n0), (a.probe & 8) ? 0u : nbytes), voffB);
         load_raw(nbi, nc, njt2);
         __syncthreads();
         // ---- phase B
         const f32x4 et = strip_gemm<MT>(tile[buf], wf, rs, q) + (vei + bu) + vej;
-        bst4(make_rsrc(a.e_tmp + e0, nbytes), voffB, et);
+        bst4(make_rsrc(rowpw(a.e_tmp, erow0), (a.probe & 4) ? 0u : nbytes), voffB, et);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = valid ? et[r] : 0.f;
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
             s2[r] += x * x;
         }
         buf ^= 1;
-        if (ONE_TILE || nu != u) {
+        if (unit_end) {
             // ---- unit end: aggregate over j, node update, statistics
             num = red16x4(num); den = red16x4(den);
             f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = num;
@@ -217,14 +229,14 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
                 for (int r = 0; r < 4; ++r) A[r] = num[r] * __builtin_amdgcn_rcpf(D[r]);      // 1 ulp reciprocal
             }
             const f32x4 xt = uxv + A;
-            bst4(make_rsrc(a.x_tmp + (size_t)u * H, H * 4), voffL, xt);
-            bst4(make_rsrc(a.Aout + (size_t)u * H, H * 4), voffL, A);
-            bst4(make_rsrc(a.Dout + (size_t)u * H, H * 4), voffL, D);
+            bst4(make_rsrc(rowpw(a.x_tmp, u), hb), voffL, xt);
+            bst4(make_rsrc(rowpw(a.Aout, u), hb), voffL, A);
+            bst4(make_rsrc(rowpw(a.Dout, u), hb), voffL, D);
             psx1 += xt; psx2 += xt * xt;
             num = f4zero(); den = f4zero();
         }
         if (!more) break;
-        u = nu; jt = njt2; bi = nbi; c = nc; vei = vei_n; uxv = uxv_n;
+        u = nu; jt = njt2; bi = nbi; c = nc; b = nb; i = ni; vei = vei_n; uxv = uxv_n;
     }
     s1 = red16x4(s1); s2 = red16x4(s2);        // edge statistics: per-lane sums over all steps, reduced once
     if (lead) {
@@ -337,34 +349,48 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
     const int njt = (V + 15) / 16;
     const int nit = (V + IT - 1) / IT;
     const int units = a.B * nit * njt * C;
-    const size_t Rn = (size_t)a.B * V * C;
+    const uint32_t Rn = (uint32_t)a.B * V * C;
     __syncthreads();
-    int u = blockIdx.x, buf = 0;
+    // contiguous range of units ((b, it, jt, c), c fastest) per workgroup; counters instead of divisions,
+    // 32-bit row indices with one widening multiply by the row bytes
+    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    if (u0 >= u1) {                                    // uniform: no units for this workgroup
+        if (do_next && lead) {
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, na1);
+            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, na1);
+        }
+        return;
+    }
+    const uint32_t hb = (uint32_t)H * 4;               // bytes of one row
+    auto rowp = [&](const float* base, uint32_t row) { return (const float*)((const char*)base + (uint64_t)row * hb); };
+    auto rowpw = [&](float* base, uint32_t row) { return (float*)((char*)base + (uint64_t)row * hb); };
+    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + hb; };
+    int u = u0, buf = 0;
     int c, jt, it, b;
-    auto decode = [&](int uu, int& c_, int& jt_, int& it_, int& b_) {
-        int tt = uu;
-        c_ = tt % C; tt /= C;
-        jt_ = tt % njt; tt /= njt;
-        it_ = tt % nit;
-        b_ = tt / nit;
-    };
-    auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + (uint32_t)H * 4; };
+    {
+        int tt = u;
+        c = tt % C; tt /= C;
+        jt = tt % njt; tt /= njt;
+        it = tt % nit;
+        b = tt / nit;
+    }
     f32x4 r_dn, r_tp, r_dxn, r_xt, r_Dv, r_ai, vnj;
     auto load_raw = [&](int b_, int c_, int jt_, int i_) {
-        const size_t nrow_i = (size_t)(b_ * V + i_) * C + c_;
-        const size_t e0 = (((size_t)(b_ * V + i_) * V + jt_ * 16) * C + c_) * (size_t)H;
+        const uint32_t bVi = (uint32_t)b_ * V + i_;
+        const uint32_t nrow_i = bVi * C + c_;
+        const uint32_t erow0 = (bVi * V + jt_ * 16) * C + c_;
         const uint32_t nb = tile_bytes(jt_);
-        r_dn = bld4(make_rsrc(a.de + e0, nb), voffA);
-        r_tp = bld4(make_rsrc(a.e_tmp + e0, nb), voffA);
-        r_dxn = bld4(make_rsrc(a.dx + nrow_i * H, H * 4), voffNA);
-        r_xt = bld4(make_rsrc(a.x_tmp + nrow_i * H, H * 4), voffNA);
-        r_Dv = bld4(make_rsrc(a.Dn + nrow_i * H, H * 4), voffNA);
-        r_ai = bld4(make_rsrc(a.Aagg + nrow_i * H, H * 4), voffNA);
+        r_dn = bld4(make_rsrc(rowp(a.de, erow0), nb), voffA);
+        r_tp = bld4(make_rsrc(rowp(a.e_tmp, erow0), nb), voffA);
+        r_dxn = bld4(make_rsrc(rowp(a.dx, nrow_i), hb), voffNA);
+        r_xt = bld4(make_rsrc(rowp(a.x_tmp, nrow_i), hb), voffNA);
+        r_Dv = bld4(make_rsrc(rowp(a.Dn, nrow_i), hb), voffNA);
+        r_ai = bld4(make_rsrc(rowp(a.Aagg, nrow_i), hb), voffNA);
     };
     auto load_vnj = [&](int b_, int c_, int jt_) {
-        vnj = bld4(make_rsrc(a.Vn + ((size_t)(b_ * V + jt_ * 16) * C + c_) * (size_t)H, tile_bytes(jt_)), voffA);
+        vnj = bld4(make_rsrc(rowp(a.Vn, ((uint32_t)b_ * V + jt_ * 16) * C + c_), tile_bytes(jt_)), voffA);
     };
-    decode(u, c, jt, it, b);
     int i = it * IT, i_end = min(V, (it + 1) * IT);
     // first step's operands before every other prologue load (see k_edge_fwd3)
     load_raw(b, c, jt, i);
@@ -375,8 +401,9 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     f32x4 cve = f4zero(), cvn = f4zero();
     while (true) {
-        const size_t nrow_i = (size_t)(b * V + i) * C + c;
-        const size_t e0 = (((size_t)(b * V + i) * V + jt * 16) * C + c) * (size_t)H;
+        const uint32_t bVi = (uint32_t)b * V + i;
+        const uint32_t nrow_i = bVi * C + c;
+        const uint32_t erow0 = (bVi * V + jt * 16) * C + c;
         const uint32_t nbytes = tile_bytes(jt);
         const int ja = jt * 16 + arow;
         const bool valid_a = ja < V && acol_ok;
@@ -388,9 +415,8 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
             const f32x4 ebe = ld4(&ce[3][acol]), em1 = ld4(&ce[4][acol]), em2 = ld4(&ce[5][acol]);
             f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f}, dme = f32x4{1.f, 1.f, 1.f, 1.f};
             if (dcx.on) {
-                const uint32_t erow = (uint32_t)(((size_t)(b * V + i) * V + ja) * C + c);
-                dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), ag);
-                dme = drop_mul4(dce, drop_rowhash(dce, erow), ag);
+                dmx = drop_mul4(dcx, drop_rowhash(dcx, nrow_i), ag);
+                dme = drop_mul4(dce, drop_rowhash(dce, erow0 + (uint32_t)arow * C), ag);
             }
             f32x4 det, dpre;
 #pragma unroll
@@ -415,28 +441,32 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
                 cve[r] += det[r];
                 cvn[r] += valid_a ? qi * g : 0.f;
             }
-            bst4(make_rsrc(a.det_out + e0, nbytes), voffA, det);
+            bst4(make_rsrc(rowpw(a.det_out, erow0), nbytes), voffA, det);
             st4(&tdet[buf][arow][acol], det);
             st4(&tpre[buf][arow][acol], dpre);
         }
-        // ---- operand of this step's statistics, then the next step's phase-A operands
-        const bool valid_b = jt * 16 + rs < V && bcol_ok;
-        const f32x4 ntp = bld4(make_rsrc(ntmp + e0, nbytes), voffB);
-        int nu = u, ni = i + 1;
-        if (ni >= i_end) nu = u + gridDim.x;
-        const bool unit_end = nu != u;
-        const bool more = nu < units;
-        int nc = c, njt2 = jt, nit2 = it, nb = b, ni_end = i_end;
+        // ---- next step's coordinates
+        const bool unit_end = i + 1 >= i_end;
+        int nu = u, ni = i + 1, nc = c, njt2 = jt, nit2 = it, nb = b, ni_end = i_end;
         if (unit_end) {
-            decode(min(nu, units - 1), nc, njt2, nit2, nb);
+            nu = u + 1; nc = c + 1;
+            if (nc == C) {
+                nc = 0; njt2 = jt + 1;
+                if (njt2 == njt) { njt2 = 0; nit2 = it + 1; if (nit2 == nit) { nit2 = 0; nb = b + 1; } }
+            }
             ni = nit2 * IT; ni_end = min(V, (nit2 + 1) * IT);
         }
-        // column sums of the finished unit (dropped by the range check while the unit continues)
+        const bool more = nu < u1;
+        if (!more) { nu = u; ni = i; nc = c; njt2 = jt; nit2 = it; nb = b; ni_end = i_end; }   // last step: reload something valid
+        // ---- operand of this step's statistics, the finished unit's column sums, the next step's phase-A operands
+        const bool valid_b = jt * 16 + rs < V && bcol_ok;
+        const f32x4 ntp = bld4(make_rsrc(rowp(ntmp, erow0), nbytes), voffB);
         {
-            const size_t n0 = ((size_t)it * Rn + (size_t)(b * V + jt * 16) * C + c) * (size_t)H;
+            // dropped by the range check (zero records) while the unit continues
+            const uint32_t colrow = (uint32_t)it * Rn + ((uint32_t)b * V + jt * 16) * C + c;
             const uint32_t nbu = unit_end ? nbytes : 0u;
-            bst4(make_rsrc(a.colVe + n0, nbu), voffA, cve);
-            bst4(make_rsrc(a.colVn + n0, nbu), voffA, cvn);
+            bst4(make_rsrc(rowpw(a.colVe, colrow), nbu), voffA, cve);
+            bst4(make_rsrc(rowpw(a.colVn, colrow), nbu), voffA, cvn);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { cve[r] = unit_end ? 0.f : cve[r]; cvn[r] = unit_end ? 0.f : cvn[r]; }
         }
@@ -446,14 +476,11 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
         // ---- phase B
         const f32x4 din = strip_gemm<MT>(tdet[buf], wf, rs, q) + ld4(&tpre[buf][rs][bcol]);
         f32x4 rsum = ld4(&tdet[buf][rs][bcol]);
-        bst4(make_rsrc(a.de + e0, nbytes), voffB, din);
+        bst4(make_rsrc(rowpw(a.de, erow0), nbytes), voffB, din);
         {
             const f32x4 nmu = ld4(&ncl[0][bcol]), nrs = ld4(&ncl[1][bcol]), nga = ld4(&ncl[2][bcol]), nbe = ld4(&ncl[3][bcol]);
             f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (ndc.on) {
-                const uint32_t erow_b = (uint32_t)(((size_t)(b * V + i) * V + jt * 16 + rs) * C + c);
-                dm = drop_mul4(ndc, drop_rowhash(ndc, erow_b), bcol >> 2);
-            }
+            if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, erow0 + (uint32_t)rs * C), bcol >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float xh = (ntp[r] - nmu[r]) * nrs[r];
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
             }
         }
         rsum = red16x4(rsum);      // invalid rows hold zeros in the tile
-        bst4(make_rsrc(a.rowpart + ((size_t)jt * Rn + nrow_i) * H, H * 4), voffL, rsum);
+        bst4(make_rsrc(rowpw(a.rowpart, (uint32_t)jt * Rn + nrow_i), hb), voffL, rsum);
         buf ^= 1;
         if (!more) break;
         u = nu; i = ni; b = nb; c = nc; jt = njt2; it = nit2; i_end = ni_end;
