@@ -289,15 +289,13 @@ void bn_finish_job(ReduceJob& j, const float* partial, int nP, int H, double n, 
     j.rd.off[0] = 0; j.rd.off[1] = H; j.rd.off[2] = 2 * H;
 }
 
-// Backward of one layer.  On entry bpart_e / bpart_x hold npart_e / npart_x rows of this layer's
-// BatchNorm-backward partial sums; with fin_first they are reduced here first, otherwise the caller's
-// previous reduce launch has already produced bstats_e / bstats_x and this layer's BatchNorm gradients.
-// On return, if nx.on, the same holds for the layer below (its partial sums come out of this layer's
-// kernels and are reduced by this layer's final reduce launch).
+// Backward of one layer, data path: edge kernel, node kernel.  bstats_e / bstats_x and this layer's BatchNorm
+// gradients must be finished (with fin_first they are reduced here from npart_e / npart_x partial rows).  On
+// return, if nx.on, bpart_e / bpart_x hold npart_e / npart_x partial rows of the layer below.
 // wT: transposed node_feat.U, node_feat.V, edge_feat.U, edge_feat.V weights of this layer.
 template <int MT>
-int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
-                   const float* x_in, const float* e_in, const float* const* P, const float* const* wT, const LayerSaved& S,
+int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
+                   const float* const* P, const float* const* wT, const LayerSaved& S,
                    float* dx, float* de, float* const* G, const LayerBwdWs& W, int& npart_e, int& npart_x,
                    const NextLayer& nx, bool fin_first, hipStream_t st) {
     const int H = d.H;
@@ -324,8 +322,8 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
             a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
         }
         const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-        int blocks = strip_blocks(units, kEdgeGrid);
-        if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = strip_blocks(units, std::min(atoi(e), 2048));
+        int blocks = range_blocks(units, kEdgeGrid);
+        if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
         GCN_PROF_PRE("k_edge_bwd3");
         k_edge_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
         GCN_CHECK_LAUNCH("k_edge_bwd3");
@@ -349,43 +347,35 @@ int layer_bwd_core(const Dims& d, int agg, float p, int training, const unsigned
         GCN_CHECK_LAUNCH("k_node_bwd3");
         if (nx.on) npart_x = blocks;
     }
-    const int slab = H * H + H;
-    {
-        // one launch for the four weight-gradient products of the layer
-        TnProblems pr = {};
-        pr.X[0] = W.det; pr.Y[0] = e_in;     // edge_feat.U
-        pr.X[1] = W.dxtmp; pr.Y[1] = x_in;   // node_feat.U
-        pr.X[2] = W.dVn; pr.Y[2] = x_in;     // node_feat.V
-        pr.X[3] = W.dVe; pr.Y[3] = x_in;     // edge_feat.V
-        pr.rows[0] = d.Re; pr.nslices[0] = W.S_e; pr.out[0] = W.tn_e; pr.out_stride[0] = slab;
-        for (int k = 1; k < 4; ++k) {
-            pr.rows[k] = d.Rn; pr.nslices[k] = W.S_n; pr.out[k] = W.tn_n + (size_t)(k - 1) * slab; pr.out_stride[k] = 3 * (size_t)slab;
-        }
-        GCN_PROF_PRE("k_gemm_tn2(layer)");
-        k_gemm_tn2<MT><<<dim3(std::max(W.S_e, W.S_n), 1, 4), 64 * MT, 0, st>>>(H, pr);
-        GCN_CHECK_LAUNCH("k_gemm_tn2(layer)");
-    }
-    {
-        ReduceJobs jobs = {};
-        jobs.n = nx.on ? 4 : 2;
-        jobs.job[0].partial = W.tn_e; jobs.job[0].nP = W.S_e; jobs.job[0].ncols = slab;
-        jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[4]; jobs.job[0].rd.dst[1] = G[5];
-        jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = H * H; jobs.job[0].rd.off[2] = slab;
-        jobs.job[1].partial = W.tn_n; jobs.job[1].nP = W.S_n; jobs.job[1].ncols = 3 * slab;
-        ReduceDst& rd = jobs.job[1].rd;
-        rd.n = 6;
-        rd.dst[0] = G[0]; rd.dst[1] = G[1]; rd.dst[2] = G[2]; rd.dst[3] = G[3]; rd.dst[4] = G[6]; rd.dst[5] = G[7];
-        for (int k = 0; k < 3; ++k) { rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H; }
-        rd.off[6] = 3 * slab;
-        if (nx.on) {
-            bn_finish_job(jobs.job[2], W.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.bstats_e);
-            bn_finish_job(jobs.job[3], W.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.bstats_x);
-        }
-        GCN_PROF_PRE("k_reduce_slabs(layer)");
-        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
-    }
     return 0;
+}
+
+// the four weight-gradient products of a layer; partial slabs go to tn_e / tn_n
+void layer_tn_problems(TnProblems& pr, const Dims& d, const LayerBwdWs& W, const float* x_in, const float* e_in, float* tn_e,
+                       float* tn_n) {
+    const size_t slab = (size_t)d.H * d.H + d.H;
+    pr.X[0] = W.det; pr.Y[0] = e_in;     // edge_feat.U
+    pr.X[1] = W.dxtmp; pr.Y[1] = x_in;   // node_feat.U
+    pr.X[2] = W.dVn; pr.Y[2] = x_in;     // node_feat.V
+    pr.X[3] = W.dVe; pr.Y[3] = x_in;     // edge_feat.V
+    pr.rows[0] = d.Re; pr.nslices[0] = W.S_e; pr.out[0] = tn_e; pr.out_stride[0] = slab;
+    for (int k = 1; k < 4; ++k) {
+        pr.rows[k] = d.Rn; pr.nslices[k] = W.S_n; pr.out[k] = tn_n + (size_t)(k - 1) * slab; pr.out_stride[k] = 3 * slab;
+    }
+}
+// the two reduce jobs that turn those slabs into the layer's weight and bias gradients
+void layer_wgrad_jobs(ReduceJob& je, ReduceJob& jn, const Dims& d, const LayerBwdWs& W, const float* tn_e, const float* tn_n,
+                      float* const* G) {
+    const int H = d.H, slab = H * H + H;
+    je.partial = tn_e; je.nP = W.S_e; je.ncols = slab;
+    je.rd.n = 2; je.rd.dst[0] = G[4]; je.rd.dst[1] = G[5];
+    je.rd.off[0] = 0; je.rd.off[1] = H * H; je.rd.off[2] = slab;
+    jn.partial = tn_n; jn.nP = W.S_n; jn.ncols = 3 * slab;
+    ReduceDst& rd = jn.rd;
+    rd.n = 6;
+    rd.dst[0] = G[0]; rd.dst[1] = G[1]; rd.dst[2] = G[2]; rd.dst[3] = G[3]; rd.dst[4] = G[6]; rd.dst[5] = G[7];
+    for (int k = 0; k < 3; ++k) { rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H; }
+    rd.off[6] = 3 * slab;
 }
 
 template <int MT>
@@ -418,7 +408,19 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
     int npe = nblk_e, npx = nblk_x;
     NextLayer none = {};
-    return layer_bwd_core<MT>(d, agg, p, training, rng, sid, x_in, e_in, P, wT, S, dx, de, G, W, npe, npx, none, true, st);
+    if (int rc = layer_bwd_data<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, G, W, npe, npx, none, true, st)) return rc;
+    TnProblems pr = {};
+    layer_tn_problems(pr, d, W, x_in, e_in, W.tn_e, W.tn_n);
+    GCN_PROF_PRE("k_gemm_tn2(layer)");
+    k_gemm_tn2<MT><<<dim3(std::max(W.S_e, W.S_n), 1, 4), 64 * MT, 0, st>>>(H, pr);
+    GCN_CHECK_LAUNCH("k_gemm_tn2(layer)");
+    ReduceJobs jobs = {};
+    jobs.n = 2;
+    layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W, W.tn_e, W.tn_n, G);
+    GCN_PROF_PRE("k_reduce_slabs(layer)");
+    k_reduce_slabs<<<dim3((3 * (H * H + H) + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+    GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
+    return 0;
 }
 
 #define DISPATCH_MT(MTV, CALL)                                   \
@@ -477,6 +479,7 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
 }
 struct ModelBwdWs {
     LayerBwdWs lw;
+    float *tn_e2, *tn_n2;           // second set of product slabs: layer l's products are written while layer l+1's are reduced
     float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
     int* emb_cnt;
     int head_blk, S_h, emb_blk;
@@ -485,6 +488,11 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     ModelBwdWs w;
     const size_t eh = p.d.Re * p.d.H;
     w.lw = carve_bwd_ws(p.d, b);
+    {
+        const size_t slab = (size_t)p.d.H * p.d.H + p.d.H;
+        w.tn_e2 = b.f((size_t)w.lw.S_e * slab);
+        w.tn_n2 = b.f((size_t)w.lw.S_n * 3 * slab);
+    }
     w.de = b.f(eh);
     w.dx = b.f(p.d.Rn * p.d.H);
     w.eL = p.NHID > 0 ? b.f(eh) : nullptr;         // output of the last conv layer, operand of the first MLP weight gradient
@@ -814,9 +822,45 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
         }
         int rc = 0;
-        DISPATCH_MT(d.MT, rc = layer_bwd_core<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, x_act + (size_t)l * nh,
-                                                  e_act + (size_t)l * eh, LP, wT, S, W.dx, W.de, LG, W.lw, npart_e, npart_x, nx, false, st));
+        DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de, LG, W.lw,
+                                                  npart_e, npart_x, nx, false, st));
         if (rc) return rc;
+        // one launch: this layer's weight-gradient products, the reduction of the layer above's products and the
+        // BatchNorm-backward finish of the layer below (its partial sums were just written)
+        float* tn_e = (l & 1) ? W.tn_e2 : W.lw.tn_e;
+        float* tn_n = (l & 1) ? W.tn_n2 : W.lw.tn_n;
+        TnProblems pr = {};
+        layer_tn_problems(pr, d, W.lw, x_act + (size_t)l * nh, e_act + (size_t)l * eh, tn_e, tn_n);
+        ReduceJobs jobs = {};
+        WgradMap map = {};
+        int nb = 0;
+        for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += pr.nslices[k]; }
+        int nj = 0;
+        if (l + 1 < p.L) {
+            float* const* UG = G + 3 + GCN_LAYER_NPARAMS * (l + 1);
+            layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, (l & 1) ? W.lw.tn_e : W.tn_e2, (l & 1) ? W.lw.tn_n : W.tn_n2, UG);
+            nj = 2;
+        }
+        if (nx.on) {
+            bn_finish_job(jobs.job[nj], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
+            bn_finish_job(jobs.job[nj + 1], W.lw.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.lw.bstats_x);
+            nj += 2;
+        }
+        jobs.n = nj;
+        for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += (jobs.job[k].ncols + 15) / 16; }
+        map.seg[8] = nb;
+        GCN_PROF_PRE("k_wgrad");
+        DISPATCH_MT(d.MT, (k_wgrad<MT><<<nb, GCN_BLOCK, 0, st>>>(H, pr, jobs, map)));
+        GCN_CHECK_LAUNCH("k_wgrad");
+    }
+    {
+        // products of layer 0 (slab set 0)
+        ReduceJobs jobs = {};
+        jobs.n = 2;
+        layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);
+        GCN_PROF_PRE("k_reduce_slabs(layer 0)");
+        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+        GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0)");
     }
     // embeddings
     GCN_PROF_PRE("k_embed_bwd_edges");

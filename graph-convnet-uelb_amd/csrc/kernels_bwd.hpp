@@ -400,15 +400,14 @@ struct ReduceJobs {
     ReduceJob job[4];
     int n;
 };
-// grid = (ceil(max ncols / 16), number of jobs)
-__global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
-    __shared__ double lds[64 * 16];
-    const ReduceJob& J = jobs.job[blockIdx.y];
+// Sum of the nP partial rows of 16 columns (colblock) of one job, in a fixed order, accumulated in fp64.
+// Needs all 256 threads of the workgroup.
+__device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int colblock, double* lds /* [64 * 16] */) {
     const float* __restrict__ partial = J.partial;
     const int nP = J.nP, ncols = J.ncols;
     const int cg = threadIdx.x & 3, pg = threadIdx.x >> 2;
-    const int col = blockIdx.x * 16 + cg * 4;
-    if (blockIdx.x * 16 >= ncols) return;          // uniform per workgroup
+    const int col = colblock * 16 + cg * 4;
+    if (colblock * 16 >= ncols) return;          // uniform per workgroup
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (col < ncols) {
         for (int p = pg; p < nP; p += 64) {
@@ -438,6 +437,11 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
                 }
         }
     }
+}
+// grid = (ceil(max ncols / 16), number of jobs)
+__global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
+    __shared__ double lds[64 * 16];
+    reduce_slab_body(jobs.job[blockIdx.y], blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -613,14 +613,21 @@ __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
 // dW rows 16w.. with MFMA operands read from LDS (A[i = n][kk = row], B[kk = row][j = k]).
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(64 * MT) void k_gemm_tn2(int H, TnProblems pr) {
-    constexpr int HP = 16 * MT, LT = HP + 16, G = 4 * MT;      // row stride 16 mod 32: conflict-free ds_read_b32
-    __shared__ __attribute__((aligned(16))) float tx[2][16][LT];
-    __shared__ __attribute__((aligned(16))) float ty[2][16][LT];
-    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+struct TnLds {
+    static constexpr int LT = 16 * MT + 16;      // row stride 16 mod 32: conflict-free ds_read_b32
+    float tx[2][16][LT];
+    float ty[2][16][LT];
+};
+// One (problem, slice) of the weight-gradient products; uses the first 64 * MT threads of the workgroup.
+template <int MT>
+__device__ __forceinline__ void gemm_tn_body(int H, const TnProblems& pr, int prob, int slice, TnLds<MT>& L) {
+    constexpr int G = 4 * MT;
+    const int t = threadIdx.x;
+    if (t >= 64 * MT) return;                         // whole wavefronts: they take no part in the barriers below
+    const int lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
     const int arow = t / G, ag = t - arow * G, acol = 4 * ag;
     const bool acol_ok = acol < H;
-    const int prob = blockIdx.z, slice = blockIdx.x, nslices = pr.nslices[prob];
+    const int nslices = pr.nslices[prob];
     if (slice >= nslices) return;                     // uniform per workgroup
     const size_t rows = pr.rows[prob];
     const float* __restrict__ X = pr.X[prob];
@@ -642,17 +649,17 @@ __global__ __launch_bounds__(64 * MT) void k_gemm_tn2(int H, TnProblems pr) {
     if (t0 < t1) fetch(t0);
     int buf = 0;
     for (size_t tile = t0; tile < t1; ++tile) {
-        st4(&tx[buf][arow][acol], xv);
-        st4(&ty[buf][arow][acol], yv);
+        st4(&L.tx[buf][arow][acol], xv);
+        st4(&L.ty[buf][arow][acol], yv);
         if (tile + 1 < t1) fetch(tile + 1);          // next tile's rows are in flight during this tile's MFMAs
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            const float av = tx[buf][4 * st + q][16 * w + rs];
+            const float av = L.tx[buf][4 * st + q][16 * w + rs];
             bsum += av;
 #pragma unroll
             for (int k = 0; k < MT; ++k)
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ty[buf][4 * st + q][16 * k + rs], acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, L.ty[buf][4 * st + q][16 * k + rs], acc[k], 0, 0, 0);
         }
         buf ^= 1;
     }
@@ -667,4 +674,29 @@ __global__ __launch_bounds__(64 * MT) void k_gemm_tn2(int H, TnProblems pr) {
     bsum = redq(bsum);
     const int n = 16 * w + rs;
     if (q == 0 && n < H) out[(size_t)H * H + n] = bsum;
+}
+
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void k_gemm_tn2(int H, TnProblems pr) {
+    __shared__ __attribute__((aligned(16))) TnLds<MT> L;
+    gemm_tn_body<MT>(H, pr, blockIdx.z, blockIdx.x, L);
+}
+
+// One launch for the work between two layers' backward data paths: the weight-gradient products of the layer
+// just finished (pr), and reduce jobs that are ready at that point (the previous layer's product slabs, the
+// BatchNorm-backward sums of the layer below).  1-D grid of 256-thread workgroups; seg[k] .. seg[k+1] are the
+// workgroups of segment k: segments 0..3 = products (one workgroup per slice), 4..7 = reduce jobs (one per 16 columns).
+struct WgradMap {
+    int seg[9];
+};
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_wgrad(int H, TnProblems pr, ReduceJobs jobs, WgradMap map) {
+    __shared__ __attribute__((aligned(16))) TnLds<MT> L;
+    __shared__ double lds[64 * 16];
+    const int bid = blockIdx.x;
+    int k = 0;
+    while (k < 7 && bid >= map.seg[k + 1]) ++k;
+    const int idx = bid - map.seg[k];
+    if (k < 4) gemm_tn_body<MT>(H, pr, k, idx, L);
+    else reduce_slab_body(jobs.job[k - 4], idx, lds);
 }
