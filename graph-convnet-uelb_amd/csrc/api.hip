@@ -96,8 +96,8 @@ int check_dims(int B, int V, int C, int H) {
 inline int wave_blocks(size_t units, int cap = 512) {
     return (int)std::max<size_t>(1, std::min<size_t>((units + GCN_WAVES_PER_BLOCK - 1) / GCN_WAVES_PER_BLOCK, (size_t)cap));
 }
-// persistent grid of the edge kernels: 256 compute units x 3 resident workgroups
-constexpr int kEdgeGrid = 768;
+// persistent grid of the edge kernels: 256 compute units x 2 resident workgroups (more did not run faster: the kernels are issue bound)
+constexpr int kEdgeGrid = 512;
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
 // grid of a kernel whose workgroups each take a contiguous range of units: no workgroup is left without work

@@ -463,7 +463,11 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
     const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][16 * MT];
     __shared__ __attribute__((aligned(16))) float nred[GCN_WAVES_PER_BLOCK][2][16 * MT];
+    // with one hidden layer its weight fragments (as stored, and transposed for the way back) live in LDS
+    constexpr bool WLDS = NHID == 1;
+    __shared__ f32x4 wl[WLDS ? 2 : 1][WLDS ? MT * MT * 64 : 1];
     edge_src_fill_consts<MT>(cl, src, H);
+    if constexpr (WLDS) { wlds_fill<MT, false>(wl[0], hp.hidW[0], H); wlds_fill<MT, true>(wl[1], hp.hidW[0], H); }
     for (int t = threadIdx.x; t < GCN_WAVES_PER_BLOCK * 2 * 16 * MT; t += blockDim.x) (&nred[0][0][0])[t] = 0.f;
     __syncthreads();
     const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
@@ -491,9 +495,14 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
         if (e_stash != nullptr) tile_store(valid ? e_stash + row * H : nullptr, H, q, h[0]);   // operand of the d W_0 GEMM
 #pragma unroll
         for (int k = 0; k < NHID; ++k) {
-            WFrag<MT> wf;
-            wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
-            const Tile<MT> o = tile_gemm(h[k], wf);
+            Tile<MT> o;
+            if constexpr (WLDS) {
+                o = tile_gemm_lds<MT>(h[k], wl[0] + lds_opaque_zero(), lane);
+            } else {
+                WFrag<MT> wf;
+                wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
+                o = tile_gemm(h[k], wf);
+            }
             const ChanVec<MT> bv = chan_load<MT>(hp.hidB[k], H, q);
             const DropCfg dc = drop_cfg(rng, stream_id0 + k, p, training);
             const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
@@ -553,9 +562,13 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
 #pragma unroll
             for (int m = 0; m < MT; ++m) dh.v[m] *= dmul[k].v[m];
             tile_store(valid ? dpre_stash + ((size_t)k * rows + row) * H : nullptr, H, q, dh);
-            WFrag<MT> wf;
-            wfrag_load_tr(wf, hp.hidW[k], H, rs, q);
-            dh = tile_gemm(dh, wf);
+            if constexpr (WLDS) {
+                dh = tile_gemm_lds<MT>(dh, wl[1] + lds_opaque_zero(), lane);
+            } else {
+                WFrag<MT> wf;
+                wfrag_load_tr(wf, hp.hidW[k], H, rs, q);
+                dh = tile_gemm(dh, wf);
+            }
         }
         tile_store(valid ? de + row * H : nullptr, H, q, dh);
         // BatchNorm-backward statistics of the last conv layer, whose apply was fused into this kernel's input

@@ -296,7 +296,11 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
     const float* __restrict__ edge_cw, float* __restrict__ logits, float* __restrict__ loss_partial,
     int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][16 * MT];
+    // with one hidden layer its weight fragments live in LDS; deeper heads read them from memory per tile
+    constexpr bool WLDS = NHID == 1;
+    __shared__ f32x4 wl[WLDS ? MT * MT * 64 : 1];
     edge_src_fill_consts<MT>(cl, src, H);
+    if constexpr (WLDS) wlds_fill<MT, false>(wl, hp.hidW[0], H);
     __syncthreads();
     const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
     const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
@@ -316,9 +320,14 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
         Tile<MT> h = edge_src_tile<MT>(src, cl, sdc, row, valid, H, C, q, nullptr, nullptr, nullptr);
 #pragma unroll
         for (int k = 0; k < NHID; ++k) {
-            WFrag<MT> wf;
-            wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
-            Tile<MT> o = tile_gemm(h, wf);
+            Tile<MT> o;
+            if constexpr (WLDS) {
+                o = tile_gemm_lds<MT>(h, wl + lds_opaque_zero(), lane);
+            } else {
+                WFrag<MT> wf;
+                wfrag_load_nt(wf, hp.hidW[k], H, rs, q);
+                o = tile_gemm(h, wf);
+            }
             const ChanVec<MT> bv = chan_load<MT>(hp.hidB[k], H, q);
             const DropCfg dc = drop_cfg(rng, stream_id0 + k, p, training);
             const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
