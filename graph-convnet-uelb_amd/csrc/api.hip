@@ -525,10 +525,10 @@ template <int MT, int NHID>
 void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const NextBn& next,
                      float* e_stash, const float* cap, const long long* y_edges, const float* edge_cw, const float* loss_out,
                      const float* dloss, const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
-                     const unsigned long long* rng, int blocks, hipStream_t st) {
+                     const unsigned long long* rng, int blocks, const ZeroJobs& z, hipStream_t st) {
     k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, next, e_stash, cap,
                                                         m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
-                                                        dloss, dy_pred, de, dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training);
+                                                        dloss, dy_pred, de, dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training, z);
 }
 
 #define DISPATCH_NHID(NH, CALL)                                  \
@@ -684,8 +684,10 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const size_t nh = d.Rn * H, eh = d.Re * H;
     float* x_act = saved + p.x_act;
     float* e_act = saved + p.e_act;
+    ZeroJobs ez = {};      // the per-(graph, commodity) counters of edge_error start at zero
+    if (m->has_labels) { ez.p[0] = reinterpret_cast<float*>(err_counts); ez.n[0] = 2 * (size_t)d.B * d.C; }
     GCN_PROF_PRE("k_embed_nodes");
-    k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act);
+    k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act, ez);
     GCN_CHECK_LAUNCH("k_embed_nodes");
     for (int l = 0; l < p.L; ++l) {
         const LayerSaved S = carve_saved(d, saved + p.lsaved + (size_t)l * p.lsaved_each);
@@ -701,9 +703,6 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
         if (rc) return rc;
     }
     const HeadParams hp = head_params(p, P);
-    if (m->has_labels) {
-        if (hipMemsetAsync(err_counts, 0, sizeof(int) * 2 * (size_t)d.B * d.C, st) != hipSuccess) return fail(-3, "memset failed");
-    }
     const PrevLayer last = prev_of(p, saved, P, p.L - 1);
     const EdgeSrc src = make_edge_src(last, nullptr, nullptr, H, m->p_layer, m->training);
     GCN_PROF_PRE("k_head_fwd");
@@ -757,16 +756,17 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     NextBn hnext = {};
     hnext.tmp = last.e_tmp; hnext.mean = last.stats; hnext.rstd = last.stats + H; hnext.gamma = last.gamma_e; hnext.beta = last.beta_e;
     hnext.drop_sid = 2 * last.sid; hnext.partial = W.lw.bpart_e;
+    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient and the
+    // BatchNorm-backward sums derived from it are zero (cleared by the head kernel on the side)
+    ZeroJobs hz = {};
+    hz.p[0] = W.dx; hz.n[0] = nh;
+    hz.p[1] = W.lw.bpart_x; hz.n[1] = 2 * (size_t)H;
     GCN_PROF_PRE("k_head_bwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
                                                                       dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
-                                                                      W.head_blk, st))));
+                                                                      W.head_blk, hz, st))));
     GCN_CHECK_LAUNCH("k_head_bwd");
     int npart_e = W.head_blk, npart_x = 1;
-    // the node output of the last layer feeds nothing (gcn_model.py:89 uses e only): its gradient and the
-    // BatchNorm-backward sums derived from it are zero
-    if (hipMemsetAsync(W.dx, 0, nh * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
-    if (hipMemsetAsync(W.lw.bpart_x, 0, 2 * (size_t)H * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
     if (p.NHID > 0) {
         TnProblems pr = {};
         for (int k = 0; k < p.NHID; ++k) {
@@ -853,27 +853,20 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         DISPATCH_MT(d.MT, (k_wgrad<MT><<<nb, GCN_BLOCK, 0, st>>>(H, pr, jobs, map)));
         GCN_CHECK_LAUNCH("k_wgrad");
     }
-    {
-        // products of layer 0 (slab set 0)
-        ReduceJobs jobs = {};
-        jobs.n = 2;
-        layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);
-        GCN_PROF_PRE("k_reduce_slabs(layer 0)");
-        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0)");
-    }
     // embeddings
     GCN_PROF_PRE("k_embed_bwd_edges");
     DISPATCH_MT(d.MT, (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
     GCN_CHECK_LAUNCH("k_embed_bwd_edges");
     {
+        // one reduce launch: products of layer 0 (slab set 0) and the edge-embedding gradient
         ReduceJobs jobs = {};
-        jobs.n = 1;
-        jobs.job[0].partial = W.embpart; jobs.job[0].nP = W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = H;
-        jobs.job[0].rd.n = 1; jobs.job[0].rd.dst[0] = G[2]; jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = H;
-        GCN_PROF_PRE("k_reduce_slabs(edge embedding)");
-        k_reduce_slabs<<<dim3((H + 15) / 16, 1, 1), GCN_BLOCK, 0, st>>>(jobs);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(edge embedding)");
+        jobs.n = 3;
+        layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);
+        jobs.job[2].partial = W.embpart; jobs.job[2].nP = W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[2].ncols = H;
+        jobs.job[2].rd.n = 1; jobs.job[2].rd.dst[0] = G[2]; jobs.job[2].rd.off[0] = 0; jobs.job[2].rd.off[1] = H;
+        GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");
+        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 3, 1), GCN_BLOCK, 0, st>>>(jobs);
+        GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0, edge embedding)");
     }
     {
         GCN_PROF_PRE("k_embed_bwd_rowsum");

@@ -137,6 +137,17 @@ __device__ __forceinline__ float redq(float x) {
 // sigmoid through the hardware exp2 / rcp (each ~1 ulp): |error| < 3e-7, far inside the 1e-4 parity budget
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Buffers a kernel clears on the side for later kernels of the same stream (saves separate fill launches).
+struct ZeroJobs {
+    float* p[2];
+    size_t n[2];      // 32-bit words
+};
+__device__ __forceinline__ void zero_fill(const ZeroJobs& z) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n[k]; i += (size_t)gridDim.x * blockDim.x) z.p[k][i] = 0.f;
+}
+
 // ---------------------------------------------------------------- counter-based dropout
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

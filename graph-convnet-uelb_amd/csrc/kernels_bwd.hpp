@@ -460,9 +460,10 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
     const float* __restrict__ dloss, const float* __restrict__ dy_pred,
     float* __restrict__ de, float* __restrict__ dpre_stash /* [NHID][rows*H] */,
     float* __restrict__ h_stash /* [NHID-1][rows*H] */, float* __restrict__ wpartial,
-    const unsigned long long* __restrict__ rng, int stream_id0, float p, int training) {
+    const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z) {
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][16 * MT];
     __shared__ __attribute__((aligned(16))) float nred[GCN_WAVES_PER_BLOCK][2][16 * MT];
+    zero_fill(z);
     // with one hidden layer its weight fragments (as stored, and transposed for the way back) live in LDS
     constexpr bool WLDS = NHID == 1;
     __shared__ f32x4 wl[WLDS ? 2 : 1][WLDS ? MT * MT * 64 : 1];

@@ -24,7 +24,8 @@ __global__ void k_embed_edges(size_t n4, int C, int H, const float* __restrict__
 // one workgroup per (b, i); thread h < H/2 handles channel h of both halves
 __global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
                               const float* __restrict__ demand, const float* __restrict__ emb,
-                              const float* __restrict__ wc, float* __restrict__ x0) {
+                              const float* __restrict__ wc, float* __restrict__ x0, ZeroJobs z) {
+    zero_fill(z);
     const int bi = blockIdx.x;          // b*V + i
     const int b = bi / V;
     const int hh = H / 2;
