@@ -47,6 +47,20 @@ def build_model(shape, device):
     return ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(device)
 
 
+def measured_traffic(config, graphs_per_gpu, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (rocprofv3 --pmc cannot run
+    inside this process); None when they were taken on another workload or kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if t.get("workload") == config and t.get("graphs_per_gpu") == graphs_per_gpu and t.get("kernel") == kernel:
+        return t.get("traffic_bytes_per_launch")
+    return None
+
+
 def cpu_baseline(shape, batch, max_seconds=25.0):
     """fwd+bwd of the CPU oracle in train mode (dropout on, as the trainer runs) on the same batch."""
     from oracle import gcn_oracle
@@ -212,7 +226,8 @@ def main():
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         step_bytes = (20.0 * Lr + 20.0) * H * Re
         roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": measured_traffic(args.config, B, DOMINANT_KERNEL),
                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches_timed": int(n.value),
                     "whole_step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)}

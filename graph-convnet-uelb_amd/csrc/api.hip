@@ -1,6 +1,7 @@
 // C ABI of libgcn_uelb_hip.so: argument checks, workspace carving and kernel launches.
 // The entry points and what they replace in the reference are documented in include/gcn_uelb_hip.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -31,21 +32,36 @@ int fail(int code, const char* fmt, ...) {
 // ---- optional per-kernel timing with HIP events (used by bench.py; off by default) -----------------
 // gcn_prof_begin(substr) arms it: every later launch whose name contains substr is bracketed by two
 // events on its own stream.  gcn_prof_end() synchronises those events and returns the summed time.
+struct ProfEvents {
+    hipEvent_t e0, e1, e2;      // e0, e1: an empty bracket recorded right before the launch; e1, e2: the launch
+};
 struct ProfState {
     bool on = false;
     char match[64] = "";
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<ProfEvents> ev;
     hipEvent_t pending = nullptr;
 };
 ProfState g_prof;
 
 inline void prof_pre(const char* name, hipStream_t st) {
     if (!g_prof.on || strstr(name, g_prof.match) == nullptr) return;
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-    (void)hipEventRecord(a, st);
-    g_prof.ev.emplace_back(a, b);
-    g_prof.pending = b;
+    ProfEvents p;
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess || hipEventCreate(&p.e2) != hipSuccess) return;
+    (void)hipEventRecord(p.e0, st);
+    (void)hipEventRecord(p.e1, st);
+    g_prof.ev.push_back(p);
+    g_prof.pending = p.e2;
+}
+// For launches made with hipExtLaunchKernelGGL: the two events receive the kernel's own begin and end time
+// stamps (what a kernel trace reports), so no bracket cost is involved.  e0 == nullptr marks such an entry.
+inline void prof_ext(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    *start = nullptr; *stop = nullptr;
+    if (!g_prof.on || strstr(name, g_prof.match) == nullptr) return;
+    ProfEvents p;
+    p.e0 = nullptr;
+    if (hipEventCreate(&p.e1) != hipSuccess || hipEventCreate(&p.e2) != hipSuccess) return;
+    g_prof.ev.push_back(p);
+    *start = p.e1; *stop = p.e2;
 }
 inline void prof_post(hipStream_t st) {
     if (g_prof.pending) { (void)hipEventRecord(g_prof.pending, st); g_prof.pending = nullptr; }
@@ -60,6 +76,16 @@ inline void prof_post(hipStream_t st) {
     } while (0)
 
 #define GCN_STREAM st
+
+// launch of one of the main kernels, timed by its own time stamps when the profiler is armed for its name
+#define GCN_LAUNCH_TIMED(name, kern, grid, block, ...)                                            \
+    do {                                                                                         \
+        hipEvent_t es_ = nullptr, ee_ = nullptr;                                                 \
+        prof_ext(name, &es_, &ee_);                                                              \
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)GCN_STREAM, es_, ee_, 0, __VA_ARGS__); \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) return fail(-3, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
 
 struct Dims {
     int B, V, C, H;
@@ -227,9 +253,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.W[1] = P[2]; a.bias[1] = P[3]; a.y[1] = S.Vn;
         a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
         a.rng = rng;
-        GCN_PROF_PRE("k_node_fwd3");
-        k_node_fwd3<MT><<<strip_blocks((d.Rn + 15) / 16), 64 * MT, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_node_fwd3");
+        GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), strip_blocks((d.Rn + 15) / 16), 64 * MT, a);
     }
     {
         EdgeFwdArgs a = {};
@@ -238,12 +262,17 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.WU = P[4]; a.bU = P[5]; a.Ve = W.Ve; a.Vn = S.Vn; a.Ux = W.Ux;
         a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
         if (const char* e = getenv("GCN_TUNE_PROBE")) a.probe = atoi(e);
-        GCN_PROF_PRE("k_edge_fwd3");
         const bool one = d.V <= 16;
-        if (a.src.mode == 0) { if (one) k_edge_fwd3<MT, 0, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 0, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
-        else if (a.src.mode == 1) { if (one) k_edge_fwd3<MT, 1, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 1, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
-        else { if (one) k_edge_fwd3<MT, 2, true><<<W.nblk, 64 * MT, 0, st>>>(a); else k_edge_fwd3<MT, 2, false><<<W.nblk, 64 * MT, 0, st>>>(a); }
-        GCN_CHECK_LAUNCH("k_edge_fwd3");
+        if (a.src.mode == 0) {
+            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, true>), W.nblk, 64 * MT, a);
+            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, false>), W.nblk, 64 * MT, a);
+        } else if (a.src.mode == 1) {
+            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, true>), W.nblk, 64 * MT, a);
+            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, false>), W.nblk, 64 * MT, a);
+        } else {
+            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, true>), W.nblk, 64 * MT, a);
+            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, false>), W.nblk, 64 * MT, a);
+        }
     }
     GCN_PROF_PRE("k_bn_stats_finalize");
     k_bn_stats_finalize<<<2 * (H / 4), GCN_BLOCK, 0, st>>>(W.partial, W.nblk, H, (double)d.Re, (double)d.Rn, S.stats);
@@ -324,9 +353,7 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
         const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
         int blocks = range_blocks(units, kEdgeGrid);
         if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
-        GCN_PROF_PRE("k_edge_bwd3");
-        k_edge_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_edge_bwd3");
+        GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
         if (nx.on) npart_e = blocks;
     }
     {
@@ -342,9 +369,7 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
             a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
         }
         const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
-        GCN_PROF_PRE("k_node_bwd3");
-        k_node_bwd3<MT><<<blocks, 64 * MT, 0, st>>>(a);
-        GCN_CHECK_LAUNCH("k_node_bwd3");
+        GCN_LAUNCH_TIMED("k_node_bwd3", (k_node_bwd3<MT>), blocks, 64 * MT, a);
         if (nx.on) npart_x = blocks;
     }
     return 0;
@@ -570,12 +595,17 @@ PrevLayer prev_of(const ModelPlan& p, const float* saved, const float* const* P,
 extern "C" {
 
 int gcn_abi_version(void) { return GCN_ABI_VERSION; }
+const char* gcn_last_error(void) { return g_err; }
+
+static void prof_clear() {
+    for (auto& e : g_prof.ev) { if (e.e0) (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
+    g_prof.ev.clear();
+    g_prof.pending = nullptr;
+}
 
 int gcn_prof_begin(const char* kernel_substr) {
     if (!kernel_substr) return fail(-1, "gcn_prof_begin: null name");
-    for (auto& e : g_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    g_prof.ev.clear();
-    g_prof.pending = nullptr;
+    prof_clear();
     strncpy(g_prof.match, kernel_substr, sizeof(g_prof.match) - 1);
     g_prof.match[sizeof(g_prof.match) - 1] = 0;
     g_prof.on = true;
@@ -587,17 +617,18 @@ int gcn_prof_end(double* total_ms, int* launches) {
     double tot = 0;
     int n = 0;
     for (auto& e : g_prof.ev) {
-        float ms = 0.f;
-        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { tot += ms; ++n; }
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+        float ms = 0.f, empty = 0.f;
+        if (hipEventSynchronize(e.e2) == hipSuccess && hipEventElapsedTime(&ms, e.e1, e.e2) == hipSuccess &&
+            (e.e0 == nullptr || hipEventElapsedTime(&empty, e.e0, e.e1) == hipSuccess)) {
+            tot += (double)ms - (double)empty;       // the event bracket's own cost, measured beside every launch
+            ++n;
+        }
     }
-    g_prof.ev.clear();
+    prof_clear();
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
     return 0;
 }
-const char* gcn_last_error(void) { return g_err; }
 
 size_t gcn_layer_saved_floats(int B, int V, int C, int H) {
     if (check_dims(B, V, C, H)) return 0;
@@ -849,9 +880,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         jobs.n = nj;
         for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += (jobs.job[k].ncols + 15) / 16; }
         map.seg[8] = nb;
-        GCN_PROF_PRE("k_wgrad");
-        DISPATCH_MT(d.MT, (k_wgrad<MT><<<nb, GCN_BLOCK, 0, st>>>(H, pr, jobs, map)));
-        GCN_CHECK_LAUNCH("k_wgrad");
+        DISPATCH_MT(d.MT, GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
     }
     // embeddings
     GCN_PROF_PRE("k_embed_bwd_edges");

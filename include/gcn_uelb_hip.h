@@ -38,9 +38,11 @@ int gcn_abi_version(void);
 const char* gcn_last_error(void);
 
 /* Measurement aid, no counterpart in the reference: after gcn_prof_begin(substr) every launch whose
- * kernel name contains substr is bracketed by two HIP events on the stream it is launched on;
- * gcn_prof_end() waits for them and returns their summed elapsed time and count.  Host-side only,
- * not for use while a stream is being captured into a graph. */
+ * kernel name contains substr is timed with HIP events on the stream it is launched on: the main layer
+ * kernels by their own begin / end time stamps (hipExtLaunchKernelGGL start / stop events), the others by
+ * an event bracket from which an empty bracket recorded beside it is subtracted.  gcn_prof_end() waits for
+ * the events and returns the summed time and the launch count.  Host-side only, not for use while a
+ * stream is being captured into a graph. */
 int gcn_prof_begin(const char* kernel_substr);
 int gcn_prof_end(double* total_ms, int* launches);
 
