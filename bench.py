@@ -128,6 +128,12 @@ def beam_bench(shape, batch, device, K=10):
             "paths_bit_exact_vs_oracle": same}
 
 
+def _stage(msg):
+    """Progress line on stderr (GCN_BENCH_VERBOSE=1): which rank reached which stage."""
+    if os.environ.get("GCN_BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,10 +161,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # GCN_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then
+        # share devices round-robin); the measured configuration is always nccl (= RCCL) with one GPU per rank
+        backend = os.environ.get("GCN_BENCH_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            if local_rank >= ndev:
+                raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible)")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % ndev
+            dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    _stage(f"process group ready, device {device}")
 
     shape = dict(CONFIGS[args.config])
     if args.batch:
@@ -167,9 +184,29 @@ def main():
     batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
                        seed=1234 + rank)
     model = build_model(shape, device).train()          # train mode: dropout active, as the trainer runs
+    staged = dist is not None and dist.get_backend() != "nccl"      # rehearsal backend: collectives go through host copies
+
+    def bcast(t):
+        if staged:
+            c = t.detach().cpu()
+            dist.broadcast(c, src=0)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=0)
+
+    def allreduce(t, op=None):
+        op = dist.ReduceOp.SUM if op is None else op
+        if staged:
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
     if dist is not None:
         for p in model.parameters():
-            dist.broadcast(p.data, src=0)
+            bcast(p.data)
+    _stage("parameters broadcast")
     step = HipTrainStep(model, B, device, use_graph=not args.no_graph)
     step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
                     batch["edges_target"], batch["edge_cw"])
@@ -178,12 +215,13 @@ def main():
     def one_step():
         step.step()
         if dist is not None:
-            dist.all_reduce(step.flat_grad)
+            allreduce(step.flat_grad)
             step.flat_grad.mul_(inv_world)
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
+    _stage("warm-up done")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,8 +235,9 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    _stage("timed steps done")
     loss = float(step.loss_out[0].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed

@@ -77,224 +77,6 @@ struct BnBwdFin {
     float* dgamma[2];
     float* dbeta[2];
 };
-__global__ __launch_bounds__(GCN_BLOCK) void k_bn_bwd_finalize(BnBwdFin a, int H) {
-    __shared__ double lds[GCN_BLOCK * 4];
-    const int col = blockIdx.x * 4;
-    const int w = blockIdx.y;
-    double s1[4], s2[4];
-    block_colsum4(a.partial[w], a.nP[w], 2 * H, col, s1, lds);
-    block_colsum4(a.partial[w], a.nP[w], 2 * H, H + col, s2, lds);
-    if (threadIdx.x == 0) {
-        for (int k = 0; k < 4; ++k) {
-            a.bstats[w][col + k] = (float)(s1[k] / a.n[w]);
-            a.bstats[w][H + col + k] = (float)(s2[k] / a.n[w]);
-            a.dbeta[w][col + k] = (float)s1[k];
-            a.dgamma[w][col + k] = (float)s2[k];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Node side, elementwise: dx_tmp = gamma*rstd*(dbn - m1 - xhat*m2) and qv = dx_tmp / D ("mean") or
-// dx_tmp ("sum"); also dpre = dx_new * dropmask (the residual branch), written to dpre_out.
-// ------------------------------------------------------------------------------------------------
-__global__ void k_node_bwd_pre(size_t rows, int H, const float* __restrict__ dnew, const float* __restrict__ tmp,
-                               const float* __restrict__ Dn, const float* __restrict__ mean,
-                               const float* __restrict__ rstd, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, const float* __restrict__ bstats,
-                               float* __restrict__ dpre_out, float* __restrict__ dxtmp, float* __restrict__ qv,
-                               const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
-    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
-    const int h4 = H / 4;
-    const size_t n4 = rows * (size_t)h4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / h4;
-        const int col = (int)(i - row * h4) * 4;
-        const f32x4 dn = *reinterpret_cast<const f32x4*>(dnew + row * H + col);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(tmp + row * H + col);
-        const f32x4 D = *reinterpret_cast<const f32x4*>(Dn + row * H + col);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(bstats + col);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(bstats + H + col);
-        const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)row) : 0u;
-        f32x4 dpre, dxt, qq;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xh = (t[k] - mu[k]) * rs[k];
-            const float bn = xh * ga[k] + be[k];
-            float d = dn[k];
-            if (dc.on) d *= drop_mul(dc, rh, col + k);
-            dpre[k] = d;
-            const float dbn = bn > 0.f ? d : 0.f;
-            const float dx = ga[k] * rs[k] * (dbn - m1[k] - xh * m2[k]);
-            dxt[k] = dx;
-            qq[k] = dx / D[k];
-        }
-        *reinterpret_cast<f32x4*>(dpre_out + row * H + col) = dpre;
-        *reinterpret_cast<f32x4*>(dxtmp + row * H + col) = dxt;
-        *reinterpret_cast<f32x4*>(qv + row * H + col) = qq;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Edge backward, main pass.  One wavefront per (b, c, i-chunk, j-tile): for each i of the chunk it
-// recomputes, for the 16 rows (b, i, j, c):
-//   dpre = de_new * dropmask ; dbn = dpre * [BN > 0] ; g = sigmoid(e_tmp)
-//   det  = gamma*rstd*(dbn - m1 - xhat*m2) + qv[b,i,c] * (Vn[b,j,c] - A[b,i,c]) * g * (1 - g)
-//   de_in = dpre + det * W_U                                   (in place over de)
-// and writes det (consumed by the weight-gradient GEMM), the row sums over j
-// (rowpart[jt][b,i,c,:]) and, accumulated in registers over the chunk's i, the column sums
-//   colVe[it][b,j,c,:] = sum_i det   and   colVn[it][b,j,c,:] = sum_i qv[b,i,c] * g .
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_edge_bwd_main(
-    int B, int V, int C, int H, int IT, int mean_agg,
-    float* __restrict__ de, const float* __restrict__ e_tmp, const float* __restrict__ WU,
-    const float* __restrict__ Vn, const float* __restrict__ Aagg, const float* __restrict__ qv,
-    const float* __restrict__ stats /* mean_e, rstd_e */, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ bstats /* m1, m2 */,
-    float* __restrict__ det_out, float* __restrict__ rowpart, float* __restrict__ colVe, float* __restrict__ colVn,
-    const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
-    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
-    const DropCfg dc = drop_cfg(rng, stream_id, p, training);
-    const int njt = (V + 15) / 16;
-    const int nit = (V + IT - 1) / IT;
-    const int units = B * nit * njt * C;
-    const size_t Rn = (size_t)B * V * C;
-    WFrag<MT> wf;
-    wfrag_load_tr(wf, WU, H, rs, q);
-    const ChanVec<MT> mu = chan_load<MT>(stats, H, q), rsd = chan_load<MT>(stats + H, H, q);
-    const ChanVec<MT> ga = chan_load<MT>(gamma, H, q), be = chan_load<MT>(beta, H, q);
-    const ChanVec<MT> m1 = chan_load<MT>(bstats, H, q), m2 = chan_load<MT>(bstats + H, H, q);
-    for (int u = wave; u < units; u += nwaves) {
-        // unit order: c fastest so that neighbouring wavefronts touch neighbouring rows
-        int t = u;
-        const int c = t % C; t /= C;
-        const int jt = t % njt; t /= njt;
-        const int it = t % nit;
-        const int b = t / nit;
-        const int j = jt * 16 + rs;
-        const bool valid = j < V;
-        const size_t nrow_j = (size_t)(b * V + j) * C + c;
-        const Tile<MT> vnj = tile_load<MT>(valid ? Vn + nrow_j * H : nullptr, H, q);
-        Tile<MT> cve, cvn;
-        tile_zero(cve); tile_zero(cvn);
-        const int i_end = min(V, (it + 1) * IT);
-        for (int i = it * IT; i < i_end; ++i) {
-            const size_t nrow_i = (size_t)(b * V + i) * C + c;
-            const ChanVec<MT> qi = chan_load<MT>(qv + nrow_i * H, H, q);
-            // "sum" aggregation has no normaliser, so d x_tmp / d gate = Vn[b,j,c] alone
-            const ChanVec<MT> ai = chan_load<MT>(mean_agg ? Aagg + nrow_i * H : nullptr, H, q);
-            const size_t erow = ((size_t)(b * V + i) * V + j) * C + c;
-            const Tile<MT> dn = tile_load<MT>(valid ? de + erow * H : nullptr, H, q);
-            const Tile<MT> tp = tile_load<MT>(valid ? e_tmp + erow * H : nullptr, H, q);
-            const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
-            Tile<MT> det, dpre;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = tp.v[m][r];
-                    const float xh = (x - mu.v[m][r]) * rsd.v[m][r];
-                    const float bn = xh * ga.v[m][r] + be.v[m][r];
-                    float d = dn.v[m][r];
-                    if (dc.on) d *= drop_mul(dc, rh, 16 * m + 4 * q + r);
-                    dpre.v[m][r] = d;
-                    const float dbn = bn > 0.f ? d : 0.f;
-                    const float g = sigmoidf_(x);
-                    float v = ga.v[m][r] * rsd.v[m][r] * (dbn - m1.v[m][r] - xh * m2.v[m][r]);
-                    v += qi.v[m][r] * (vnj.v[m][r] - ai.v[m][r]) * g * (1.f - g);
-                    v = valid ? v : 0.f;
-                    det.v[m][r] = v;
-                    cve.v[m][r] += v;
-                    cvn.v[m][r] += valid ? qi.v[m][r] * g : 0.f;
-                }
-            tile_store(valid ? det_out + erow * H : nullptr, H, q, det);
-            Tile<MT> din = tile_gemm(det, wf);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) din.v[m] += dpre.v[m];
-            tile_store(valid ? de + erow * H : nullptr, H, q, din);
-            tile_red16(det);   // row sums over the tile's j
-            if (rs == 0) {
-                float* rp = rowpart + ((size_t)jt * Rn + nrow_i) * H;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int col = 16 * m + 4 * q;
-                    if (col < H) *reinterpret_cast<f32x4*>(rp + col) = det.v[m];
-                }
-            }
-        }
-        tile_store(valid ? colVe + ((size_t)it * Rn + nrow_j) * H : nullptr, H, q, cve);
-        tile_store(valid ? colVn + ((size_t)it * Rn + nrow_j) * H : nullptr, H, q, cvn);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Node backward: gathers the partial sums, forms
-//   dVe[b,v,c] = sum_jt rowpart + sum_it colVe,  dVn[b,v,c] = sum_it colVn,  dUx = dx_tmp
-// and dx_in = dpre + dUx W_nU + dVn W_nV + dVe W_eV (in place over dx, which holds dpre on entry).
-// dVe/dVn are written out for the weight-gradient GEMMs.  One wavefront per 16-row tile.
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_node_bwd(
-    int rows, int H, int njt, int nit, const float* __restrict__ rowpart, const float* __restrict__ colVe,
-    const float* __restrict__ colVn, const float* __restrict__ dxtmp, const float* __restrict__ WnU,
-    const float* __restrict__ WnV, const float* __restrict__ WeV, float* __restrict__ dx,
-    float* __restrict__ dVe_out, float* __restrict__ dVn_out) {
-    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
-    const int ntiles = (rows + 15) / 16;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
-        const int row = tile * 16 + rs;
-        const bool valid = row < rows;
-        Tile<MT> dve, dvn;
-        tile_zero(dve); tile_zero(dvn);
-        for (int k = 0; k < njt; ++k) {
-            const Tile<MT> t = tile_load<MT>(valid ? rowpart + ((size_t)k * rows + row) * H : nullptr, H, q);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) dve.v[m] += t.v[m];
-        }
-        for (int k = 0; k < nit; ++k) {
-            const Tile<MT> t = tile_load<MT>(valid ? colVe + ((size_t)k * rows + row) * H : nullptr, H, q);
-            const Tile<MT> t2 = tile_load<MT>(valid ? colVn + ((size_t)k * rows + row) * H : nullptr, H, q);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { dve.v[m] += t.v[m]; dvn.v[m] += t2.v[m]; }
-        }
-        tile_store(valid ? dVe_out + (size_t)row * H : nullptr, H, q, dve);
-        tile_store(valid ? dVn_out + (size_t)row * H : nullptr, H, q, dvn);
-        Tile<MT> acc = tile_load<MT>(valid ? dx + (size_t)row * H : nullptr, H, q);
-        const Tile<MT> dux = tile_load<MT>(valid ? dxtmp + (size_t)row * H : nullptr, H, q);
-        {
-            WFrag<MT> wf;
-            wfrag_load_tr(wf, WnU, H, rs, q);
-            const Tile<MT> o = tile_gemm(dux, wf);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
-        }
-        {
-            WFrag<MT> wf;
-            wfrag_load_tr(wf, WnV, H, rs, q);
-            const Tile<MT> o = tile_gemm(dvn, wf);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
-        }
-        {
-            WFrag<MT> wf;
-            wfrag_load_tr(wf, WeV, H, rs, q);
-            const Tile<MT> o = tile_gemm(dve, wf);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc.v[m] += o.v[m];
-        }
-        tile_store(valid ? dx + (size_t)row * H : nullptr, H, q, acc);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM with the reduction over rows: dW[n][k] = sum_row X[row][n] * Y[row][k] and
 // db[n] = sum_row X[row][n], split over gridDim.x row slices.  Up to 3 (X, Y) problems per launch
@@ -312,73 +94,6 @@ struct TnProblems {
     float* out[4];
     size_t out_stride[4];
 };
-
-template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_gemm_tn(size_t rows, int H, int nprob, TnProblems pr,
-                                                      float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int m = blockIdx.y * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int prob = blockIdx.z;
-    const int slice = blockIdx.x, nslices = gridDim.x;
-    const float* __restrict__ X = pr.X[prob];
-    const float* __restrict__ Y = pr.Y[prob];
-    const size_t ntiles = (rows + 15) / 16;
-    const size_t per = (ntiles + nslices - 1) / nslices;
-    const size_t t0 = (size_t)slice * per, t1 = min(ntiles, t0 + per);
-    f32x4 acc[MT];
-#pragma unroll
-    for (int k = 0; k < MT; ++k) acc[k] = f4zero();
-    float bsum = 0.f;
-    const int n = 16 * m + rs;
-    if (m < MT) {
-        // operands of one 16-row tile: a[st] = X[row(st)][n], b[st][k] = Y[row(st)][16k + rs], row(st) = 16*tile + 4*st + q
-        float a_cur[4], b_cur[4][MT], a_nxt[4], b_nxt[4][MT];
-        auto load_tile = [&](size_t tile, float (&a)[4], float (&b)[4][MT]) {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const size_t row = tile * 16 + st * 4 + q;
-                const bool valid = row < rows;
-                a[st] = (valid && n < H) ? X[row * H + n] : 0.f;
-#pragma unroll
-                for (int k = 0; k < MT; ++k) {
-                    const int kc = 16 * k + rs;
-                    b[st][k] = (valid && kc < H) ? Y[row * H + kc] : 0.f;
-                }
-            }
-        };
-        if (t0 < t1) load_tile(t0, a_cur, b_cur);
-        for (size_t tile = t0; tile < t1; ++tile) {
-            const bool more = tile + 1 < t1;
-            if (more) load_tile(tile + 1, a_nxt, b_nxt);      // in flight while this tile's MFMAs run
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                bsum += a_cur[st];
-#pragma unroll
-                for (int k = 0; k < MT; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[st], b_cur[st][k], acc[k], 0, 0, 0);
-            }
-            if (more) {
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    a_cur[st] = a_nxt[st];
-#pragma unroll
-                    for (int k = 0; k < MT; ++k) b_cur[st][k] = b_nxt[st][k];
-                }
-            }
-        }
-        // D[i = n-slot 4q + r][j = k-slot rs]
-        float* out = partial + ((size_t)slice * nprob + prob) * ((size_t)H * H + H);
-#pragma unroll
-        for (int k = 0; k < MT; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nn = 16 * m + 4 * q + r, kc = 16 * k + rs;
-                if (nn < H && kc < H) out[(size_t)nn * H + kc] = acc[k][r];
-            }
-        bsum = redq(bsum);
-        if (q == 0 && n < H) out[(size_t)H * H + n] = bsum;
-    }
-}
 
 // Sum of nP partial slabs of ncols floats (ncols % 4 == 0) -> up to 8 destination tensors: column range
 // [off[d], off[d+1]) of the slab goes to dst[d].  One workgroup per 16 columns: thread (pg, cg) adds

@@ -4,23 +4,6 @@
 #include "common.hpp"
 #include "kernels_fused.hpp"
 
-// ------------------------------------------------------------------------------------------------
-// Embedding stage.  Mirrors ResidualGatedGCNModel.forward, src/gcn/models/gcn_model.py:68-84.
-//   e0[b,i,j,c,:] = cap[b,i,j] * w_e            x0[b,i,c,:H/2] = mean_c' Emb[x_nodes[b,i,c']]
-//                                               x0[b,i,c,H/2:] = demand[b,c] * w_c
-// ------------------------------------------------------------------------------------------------
-__global__ void k_embed_edges(size_t n4, int C, int H, const float* __restrict__ cap,
-                              const float* __restrict__ we, float* __restrict__ e0) {
-    const int h4 = H / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / h4;
-        const int col = (int)(i - row * h4) * 4;
-        const float cv = cap[row / C];
-        const f32x4 w = *reinterpret_cast<const f32x4*>(we + col);
-        *reinterpret_cast<f32x4*>(e0 + row * H + col) = w * cv;
-    }
-}
-
 // one workgroup per (b, i); thread h < H/2 handles channel h of both halves
 __global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
                               const float* __restrict__ demand, const float* __restrict__ emb,
@@ -43,154 +26,6 @@ __global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* _
             row[h] = mean;
             row[hh + h] = demand[(size_t)b * C + c] * w;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Node-side linears of one layer: Ux = x W_nU^T + b, Vn = x W_nV^T + b (NodeFeatures.forward,
-// src/gcn/models/gcn_layers.py:63-64) and Ve = x W_eV^T + b (EdgeFeatures.forward, :90).
-// One wavefront per 16-row tile.
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_node_gemm3(
-    int rows, int H, const float* __restrict__ x,
-    const float* __restrict__ W0, const float* __restrict__ b0, float* __restrict__ y0,
-    const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ y1,
-    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ y2) {
-    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
-    const int ntiles = (rows + 15) / 16;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
-        const int row = tile * 16 + rs;
-        const bool valid = row < rows;
-        const Tile<MT> in = tile_load<MT>(valid ? x + (size_t)row * H : nullptr, H, q);
-#pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            const float* W = which == 0 ? W0 : (which == 1 ? W1 : W2);
-            const float* bias = which == 0 ? b0 : (which == 1 ? b1 : b2);
-            float* y = which == 0 ? y0 : (which == 1 ? y1 : y2);
-            WFrag<MT> wf;
-            wfrag_load_nt(wf, W, H, rs, q);
-            Tile<MT> out = tile_gemm(in, wf);
-            const ChanVec<MT> bv = chan_load<MT>(bias, H, q);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) out.v[m] += bv.v[m];
-            tile_store(valid ? y + (size_t)row * H : nullptr, H, q, out);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Edge pass 1 of a layer.  One wavefront per (b, i, c); it walks the 16-row j tiles of that
-// (b, i, c) slice (rows are C*H floats apart), and per tile does
-//   e_tmp = e_in W_U^T + b_U + Ve[b,i,c] + Ve[b,j,c]          (EdgeFeatures.forward, gcn_layers.py:89-93)
-//   gate  = sigmoid(e_tmp)                                     (:120)
-//   num  += gate * Vn[b,j,c] ; den += gate                     (NodeFeatures.forward, :65-69)
-// then x_tmp[b,i,c] = Ux + num / (1e-20 + den) ("mean") or Ux + num ("sum"), and per-wavefront partial
-// sums of e_tmp, e_tmp^2, x_tmp, x_tmp^2 per channel for the two BatchNorms (:122-123).
-// partial layout: [nblocks][4][H].
-// ------------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_edge_fwd(
-    int B, int V, int C, int H, int mean_agg,
-    const float* __restrict__ e_in, const float* __restrict__ WU, const float* __restrict__ bU,
-    const float* __restrict__ Ve, const float* __restrict__ Vn, const float* __restrict__ Ux,
-    float* __restrict__ e_tmp, float* __restrict__ x_tmp, float* __restrict__ Aout, float* __restrict__ Dout,
-    float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
-    WFrag<MT> wf;
-    wfrag_load_nt(wf, WU, H, rs, q);
-    const ChanVec<MT> bu = chan_load<MT>(bU, H, q);
-    Tile<MT> s1, s2, sx1, sx2;
-    tile_zero(s1); tile_zero(s2); tile_zero(sx1); tile_zero(sx2);
-    const int units = B * V * C;
-    const int njt = (V + 15) / 16;
-    for (int u = wave; u < units; u += nwaves) {
-        const int b = u / (V * C);
-        const int rem = u - b * V * C;
-        const int i = rem / C;
-        const int c = rem - i * C;
-        const size_t nrow_i = (size_t)(b * V + i) * C + c;
-        ChanVec<MT> vei = chan_load<MT>(Ve + nrow_i * H, H, q);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) vei.v[m] += bu.v[m];
-        Tile<MT> num, den;
-        tile_zero(num); tile_zero(den);
-        for (int jt = 0; jt < njt; ++jt) {
-            const int j = jt * 16 + rs;
-            const bool valid = j < V;
-            const float vf = valid ? 1.f : 0.f;
-            const size_t erow = ((size_t)(b * V + i) * V + j) * C + c;
-            const size_t nrow_j = (size_t)(b * V + j) * C + c;
-            const Tile<MT> in = tile_load<MT>(valid ? e_in + erow * H : nullptr, H, q);
-            const Tile<MT> vej = tile_load<MT>(valid ? Ve + nrow_j * H : nullptr, H, q);
-            const Tile<MT> vnj = tile_load<MT>(valid ? Vn + nrow_j * H : nullptr, H, q);
-            Tile<MT> et = tile_gemm(in, wf);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                et.v[m] += vei.v[m] + vej.v[m];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = et.v[m][r];
-                    const float g = sigmoidf_(x) * vf;
-                    num.v[m][r] += g * vnj.v[m][r];
-                    den.v[m][r] += g;
-                    s1.v[m][r] += x * vf;
-                    s2.v[m][r] += x * x * vf;
-                }
-            }
-            tile_store(valid ? e_tmp + erow * H : nullptr, H, q, et);
-        }
-        tile_red16(num);
-        tile_red16(den);
-        if (rs == 0) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int col = 16 * m + 4 * q;
-                if (col < H) {
-                    const f32x4 ux = *reinterpret_cast<const f32x4*>(Ux + nrow_i * H + col);
-                    f32x4 D, A;
-                    if (mean_agg) {
-                        D = den.v[m] + 1e-20f;
-                        A = num.v[m] / D;
-                    } else {
-                        D = f32x4{1.f, 1.f, 1.f, 1.f};
-                        A = num.v[m];
-                    }
-                    const f32x4 xt = ux + A;
-                    *reinterpret_cast<f32x4*>(x_tmp + nrow_i * H + col) = xt;
-                    *reinterpret_cast<f32x4*>(Aout + nrow_i * H + col) = A;
-                    *reinterpret_cast<f32x4*>(Dout + nrow_i * H + col) = D;
-                    sx1.v[m] += xt;
-                    sx2.v[m] += xt * xt;
-                }
-            }
-        }
-    }
-    tile_red16(s1);
-    tile_red16(s2);
-    // workgroup partial = sum of its 4 wavefronts in wavefront order (through LDS): one slab per workgroup
-    __shared__ float red[GCN_WAVES_PER_BLOCK][4][16 * MT];
-    const int wv = threadIdx.x >> 6;
-    if (rs == 0) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            *reinterpret_cast<f32x4*>(&red[wv][0][16 * m + 4 * q]) = s1.v[m];
-            *reinterpret_cast<f32x4*>(&red[wv][1][16 * m + 4 * q]) = s2.v[m];
-            *reinterpret_cast<f32x4*>(&red[wv][2][16 * m + 4 * q]) = sx1.v[m];
-            *reinterpret_cast<f32x4*>(&red[wv][3][16 * m + 4 * q]) = sx2.v[m];
-        }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 4 * H; t += blockDim.x) {
-        const int which = t / H, col = t - which * H;
-        float v = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < GCN_WAVES_PER_BLOCK; ++w2) v += red[w2][which][col];
-        partial[(size_t)blockIdx.x * 4 * H + t] = v;
     }
 }
 

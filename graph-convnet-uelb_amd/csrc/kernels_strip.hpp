@@ -91,7 +91,7 @@ __device__ __forceinline__ f32x4 red16x4(f32x4 v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge forward of layer l (same math and arguments as k_edge_fwd2; MODE = EdgeSrc::mode).  Persistent
+// Edge forward of layer l (math: see EdgeFwdArgs; MODE = EdgeSrc::mode).  Persistent
 // workgroups walk steps = ((b, i, c) unit, 16-row j tile).  The loop body is straight-line: loads use
 // clamped (always valid) coordinates and results are masked, so the compiler can keep the loads of step
 // n+1 in flight across the MFMA phase of step n (vector-memory operations retire in issue order: the
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Node forward of layer l (same math and arguments as k_node_fwd2): one workgroup per 16-row tile;
+// Node forward of layer l (math: see NodeFwdArgs): one workgroup per 16-row tile;
 // each wavefront produces its column block of all three linears.
 // ------------------------------------------------------------------------------------------------
 template <int MT>
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * MT) void k_node_fwd3(NodeFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge backward of layer l (same math and arguments as k_edge_bwd_main2).  Persistent workgroups walk
+// Edge backward of layer l (math: see EdgeBwdArgs).  Persistent workgroups walk
 // steps = ((b, c, i-chunk, j-tile) unit, i of the chunk); straight-line loop body with clamped loads as in
 // k_edge_fwd3.
 // ------------------------------------------------------------------------------------------------
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Node backward of layer l (same math and arguments as k_node_bwd2): one workgroup per 16-row tile.
+// Node backward of layer l (math: see NodeBwdArgs): one workgroup per 16-row tile.
 // ------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight-gradient GEMM dW[n][k] = sum_row X[row][n] * Y[row][k], db[n] = sum_row X[row][n] (same partial
-// layout as k_gemm_tn: [slice][prob][H*H + H]).  One workgroup per (row slice, problem); per 16-row tile
+// Weight-gradient GEMM dW[n][k] = sum_row X[row][n] * Y[row][k], db[n] = sum_row X[row][n] (each (problem,
+// slice) writes a slab of H*H + H floats).  One workgroup per (row slice, problem); per 16-row tile
 // the workgroup stages X and Y rows coalesced into LDS, wavefront w then accumulates the 16 x H block of
 // dW rows 16w.. with MFMA operands read from LDS (A[i = n][kk = row], B[kk = row][j = k]).
 // ------------------------------------------------------------------------------------------------
