@@ -138,7 +138,7 @@ def model_forward(P, cfg, x_edges_capacity, x_commodities, x_nodes, y_edges=None
     if compute_loss:
         if y_edges is None or edge_cw is None:
             raise ValueError("y_edges and edge_cw required when compute_loss=True")
-        loss = loss_edges(y, y_edges, torch.as_tensor(edge_cw, dtype=torch.float32))
+        loss = loss_edges(y, y_edges, torch.as_tensor(edge_cw).to(y.dtype))
     if return_layers:
         return y, loss, layers
     return y, loss
