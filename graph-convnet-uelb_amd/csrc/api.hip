@@ -16,6 +16,7 @@
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
 #include "kernels_strip.hpp"
+#include "kernels_wide.hpp"
 
 namespace {
 
@@ -253,7 +254,8 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.W[1] = P[2]; a.bias[1] = P[3]; a.y[1] = S.Vn;
         a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
         a.rng = rng;
-        GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), strip_blocks((d.Rn + 15) / 16), 64 * MT, a);
+        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_fwd_w", k_node_fwd_w, strip_blocks((d.Rn + 15) / 16), 256, a);
+        else GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), strip_blocks((d.Rn + 15) / 16), 64 * MT, a);
     }
     {
         EdgeFwdArgs a = {};
@@ -263,15 +265,23 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
         if (const char* e = getenv("GCN_TUNE_PROBE")) a.probe = atoi(e);
         const bool one = d.V <= 16;
-        if (a.src.mode == 0) {
-            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, true>), W.nblk, 64 * MT, a);
-            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, false>), W.nblk, 64 * MT, a);
+        if constexpr (MT == 0) {
+            GCN_LAUNCH_TIMED("k_edge_fwd_w", k_edge_fwd_w, W.nblk, 256, a);
+        } else if (a.src.mode == 0) {
+            if constexpr (MT != 0) {
+                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, true>), W.nblk, 64 * MT, a);
+                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, false>), W.nblk, 64 * MT, a);
+            }
         } else if (a.src.mode == 1) {
-            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, true>), W.nblk, 64 * MT, a);
-            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, false>), W.nblk, 64 * MT, a);
+            if constexpr (MT != 0) {
+                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, true>), W.nblk, 64 * MT, a);
+                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, false>), W.nblk, 64 * MT, a);
+            }
         } else {
-            if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, true>), W.nblk, 64 * MT, a);
-            else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, false>), W.nblk, 64 * MT, a);
+            if constexpr (MT != 0) {
+                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, true>), W.nblk, 64 * MT, a);
+                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, false>), W.nblk, 64 * MT, a);
+            }
         }
     }
     GCN_PROF_PRE("k_bn_stats_finalize");
@@ -353,7 +363,8 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
         const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
         int blocks = range_blocks(units, kEdgeGrid);
         if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
-        GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
+        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
+        else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
         if (nx.on) npart_e = blocks;
     }
     {
@@ -369,7 +380,8 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
             a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
         }
         const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
-        GCN_LAUNCH_TIMED("k_node_bwd3", (k_node_bwd3<MT>), blocks, 64 * MT, a);
+        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_bwd_w", k_node_bwd_w, blocks, 256, a);
+        else GCN_LAUNCH_TIMED("k_node_bwd3", (k_node_bwd3<MT>), blocks, 64 * MT, a);
         if (nx.on) npart_x = blocks;
     }
     return 0;
@@ -388,6 +400,16 @@ void layer_tn_problems(TnProblems& pr, const Dims& d, const LayerBwdWs& W, const
         pr.rows[k] = d.Rn; pr.nslices[k] = W.S_n; pr.out[k] = tn_n + (size_t)(k - 1) * slab; pr.out_stride[k] = 3 * slab;
     }
 }
+// launch of weight-gradient products (nprob problems, at most max_slices row slices each)
+template <int MT>
+int launch_tn(int H, const TnProblems& pr, int nprob, int max_slices, hipStream_t st) {
+    GCN_PROF_PRE("k_gemm_tn");
+    if constexpr (MT == 0) k_gemm_tn_w<<<dim3(max_slices, ((H + 15) / 16 + 3) / 4, nprob), 256, 0, st>>>(H, pr);
+    else k_gemm_tn2<MT><<<dim3(max_slices, 1, nprob), 64 * MT, 0, st>>>(H, pr);
+    GCN_CHECK_LAUNCH("k_gemm_tn");
+    return 0;
+}
+
 // the two reduce jobs that turn those slabs into the layer's weight and bias gradients
 void layer_wgrad_jobs(ReduceJob& je, ReduceJob& jn, const Dims& d, const LayerBwdWs& W, const float* tn_e, const float* tn_n,
                       float* const* G) {
@@ -424,21 +446,27 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     if (int rc = transpose_layer_weights<MT>(P, wTbuf, wT, H, st)) return rc;
     const int nblk_e = wave_blocks((d.Re + 15) / 16), nblk_x = wave_blocks((d.Rn + 15) / 16);
     GCN_PROF_PRE("k_bn_bwd_stats(edges)");
-    k_bn_bwd_stats<MT><<<nblk_e, GCN_BLOCK, 0, st>>>(d.Re, H, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11], W.bpart_e, rng,
-                                                     2 * sid, p, training);
+    if constexpr (MT == 0)
+        k_colsum_w<true><<<nblk_e, 256, 0, st>>>(d.Re, H, d.C, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11], nullptr, W.bpart_e,
+                                                 rng, 2 * sid, p, training);
+    else
+        k_bn_bwd_stats<MT><<<nblk_e, GCN_BLOCK, 0, st>>>(d.Re, H, de, S.e_tmp, S.stats, S.stats + H, P[10], P[11], W.bpart_e, rng,
+                                                         2 * sid, p, training);
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(edges)");
     GCN_PROF_PRE("k_bn_bwd_stats(nodes)");
-    k_bn_bwd_stats<MT><<<nblk_x, GCN_BLOCK, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9],
-                                                     W.bpart_x, rng, 2 * sid + 1, p, training);
+    if constexpr (MT == 0)
+        k_colsum_w<true><<<nblk_x, 256, 0, st>>>(d.Rn, H, d.C, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9], nullptr,
+                                                 W.bpart_x, rng, 2 * sid + 1, p, training);
+    else
+        k_bn_bwd_stats<MT><<<nblk_x, GCN_BLOCK, 0, st>>>(d.Rn, H, dx, S.x_tmp, S.stats + 2 * H, S.stats + 3 * H, P[8], P[9],
+                                                         W.bpart_x, rng, 2 * sid + 1, p, training);
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
     int npe = nblk_e, npx = nblk_x;
     NextLayer none = {};
     if (int rc = layer_bwd_data<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, G, W, npe, npx, none, true, st)) return rc;
     TnProblems pr = {};
     layer_tn_problems(pr, d, W, x_in, e_in, W.tn_e, W.tn_n);
-    GCN_PROF_PRE("k_gemm_tn2(layer)");
-    k_gemm_tn2<MT><<<dim3(std::max(W.S_e, W.S_n), 1, 4), 64 * MT, 0, st>>>(H, pr);
-    GCN_CHECK_LAUNCH("k_gemm_tn2(layer)");
+    if (int rc = launch_tn<MT>(H, pr, 4, std::max(W.S_e, W.S_n), st)) return rc;
     ReduceJobs jobs = {};
     jobs.n = 2;
     layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W, W.tn_e, W.tn_n, G);
@@ -454,7 +482,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
         case 2: { constexpr int MT = 2; CALL; } break;           \
         case 3: { constexpr int MT = 3; CALL; } break;           \
         case 4: { constexpr int MT = 4; CALL; } break;           \
-        default: return fail(-1, "unsupported hidden_dim tile count %d", MTV); \
+        default: { constexpr int MT = 0; CALL; } break;          /* hidden_dim > 64: the wide kernels */ \
     }
 
 // ---- model-level plans -----------------------------------------------------------------------------
@@ -481,7 +509,8 @@ int check_model(const gcn_model_desc* m) {
     if (m == nullptr) return fail(-1, "null model descriptor");
     if (int rc = check_dims(m->B, m->V, m->C, m->H)) return rc;
     if (m->L < 1) return fail(-1, "num_layers %d < 1", m->L);
-    if (m->L > 15) return fail(-1, "num_layers %d > 15 is not supported by this build", m->L);
+    if (m->L > 64) return fail(-1, "num_layers %d > 64 is not supported by this build", m->L);
+    if (m->H > 64 && m->mlp_layers > 2) return fail(-1, "hidden_dim %d > 64 supports mlp_layers <= 2 (got %d)", m->H, m->mlp_layers);
     if (m->mlp_layers < 1 || m->mlp_layers > GCN_MAX_MLP_LAYERS) return fail(-1, "mlp_layers %d outside 1..%d", m->mlp_layers, GCN_MAX_MLP_LAYERS);
     if (m->voc_out != 1 && m->voc_out != 2) return fail(-1, "voc_edges_out %d must be 1 or 2", m->voc_out);
     if (m->H % 2 != 0) return fail(-1, "hidden_dim must be even");
@@ -541,6 +570,12 @@ template <int MT, int NHID>
 void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const float* cap,
                      const long long* y_edges, const float* edge_cw, float* y_pred, float* loss_partial, int* counts,
                      const unsigned long long* rng, int blocks, hipStream_t st) {
+    if constexpr (MT == 0) {
+        if constexpr (NHID <= 1)
+            k_head_fwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
+                                                       m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                       m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
+    } else
     k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
                                                         m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
                                                         m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp,
@@ -550,7 +585,13 @@ template <int MT, int NHID>
 void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const NextBn& next,
                      float* e_stash, const float* cap, const long long* y_edges, const float* edge_cw, const float* loss_out,
                      const float* dloss, const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
-                     const unsigned long long* rng, int blocks, const ZeroJobs& z, hipStream_t st) {
+                     const unsigned long long* rng, int blocks, const ZeroJobs& z, const float* hidWt, hipStream_t st) {
+    if constexpr (MT == 0) {
+        if constexpr (NHID <= 1)
+            k_head_bwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, hidWt, src, next, e_stash, cap,
+                                                       m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
+                                                       dloss, dy_pred, de, dpre, wpartial, rng, 1000, m->p_mlp, m->training, z);
+    } else
     k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, next, e_stash, cap,
                                                         m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
                                                         dloss, dy_pred, de, dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training, z);
@@ -742,7 +783,7 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     GCN_CHECK_LAUNCH("k_head_fwd");
     if (m->has_labels) {
         GCN_PROF_PRE("k_loss_finalize");
-        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
+        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, d.MT > 4 ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
                                                  err_flags);
         GCN_CHECK_LAUNCH("k_loss_finalize");
     }
@@ -770,16 +811,21 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     const HeadParams hp = head_params(p, P);
     const int hbase = 3 + GCN_LAYER_NPARAMS * p.L;
     const int slab = H * H + H;
-    // transposed copies of every H x H weight used in an "X * W" product of the backward pass
+    // transposed copies of every H x H weight used in an "X * W" product of the backward pass (64 per launch)
     {
-        TransposeList tl = {};
-        int n = 0;
+        std::vector<std::pair<const float*, float*>> tr;
         const int idx[4] = {0, 2, 4, 6};
         for (int l = 0; l < p.L; ++l)
-            for (int k = 0; k < 4; ++k) { tl.src[n] = P[3 + GCN_LAYER_NPARAMS * l + idx[k]]; tl.dst[n] = W.wT + (size_t)n * hh2; ++n; }
-        GCN_PROF_PRE("k_transpose_weights");
-        k_transpose_weights<<<n, GCN_BLOCK, 0, st>>>(tl, H);
-        GCN_CHECK_LAUNCH("k_transpose_weights");
+            for (int k = 0; k < 4; ++k) tr.emplace_back(P[3 + GCN_LAYER_NPARAMS * l + idx[k]], W.wT + (size_t)(4 * l + k) * hh2);
+        if (d.MT > 4 && p.NHID == 1) tr.emplace_back(hp.hidW[0], W.wT + (size_t)4 * p.L * hh2);   // the wide head reads W_0^T
+        for (size_t i0 = 0; i0 < tr.size(); i0 += 64) {
+            TransposeList tl = {};
+            const int n = (int)std::min<size_t>(64, tr.size() - i0);
+            for (int k = 0; k < n; ++k) { tl.src[k] = tr[i0 + k].first; tl.dst[k] = tr[i0 + k].second; }
+            GCN_PROF_PRE("k_transpose_weights");
+            k_transpose_weights<<<n, GCN_BLOCK, 0, st>>>(tl, H);
+            GCN_CHECK_LAUNCH("k_transpose_weights");
+        }
     }
     float* dpre_all = p.NHID == 1 ? W.lw.det : W.dpre_stash;   // [NHID][Re*H], see carve_model_bwd
     const PrevLayer last = prev_of(p, saved, P, p.L - 1);
@@ -795,7 +841,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     GCN_PROF_PRE("k_head_bwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
                                                                       dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
-                                                                      W.head_blk, hz, st))));
+                                                                      W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2, st))));
     GCN_CHECK_LAUNCH("k_head_bwd");
     int npart_e = W.head_blk, npart_x = 1;
     if (p.NHID > 0) {
@@ -807,15 +853,15 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         for (int k = 0; k < p.NHID; ++k) {
             pr.rows[k] = d.Re; pr.nslices[k] = W.S_h; pr.out[k] = W.tn_h + (size_t)k * slab; pr.out_stride[k] = (size_t)p.NHID * slab;
         }
-        GCN_PROF_PRE("k_gemm_tn2(head)");
-        DISPATCH_MT(d.MT, (k_gemm_tn2<MT><<<dim3(W.S_h, 1, p.NHID), 64 * MT, 0, st>>>(H, pr)));
-        GCN_CHECK_LAUNCH("k_gemm_tn2(head)");
+        int rc = 0;
+        DISPATCH_MT(d.MT, rc = launch_tn<MT>(H, pr, p.NHID, W.S_h, st));
+        if (rc) return rc;
     }
     {
         const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
         // output-layer gradients, hidden-layer weight gradients and the BatchNorm backward of the top layer
         ReduceJobs jobs = {};
-        jobs.job[0].partial = W.wpartial; jobs.job[0].nP = W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
+        jobs.job[0].partial = W.wpartial; jobs.job[0].nP = d.MT > 4 ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
         jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[hbase + 2 * p.NHID]; jobs.job[0].rd.dst[1] = G[hbase + 2 * p.NHID + 1];
         jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = p.voc * H; jobs.job[0].rd.off[2] = p.voc * H + p.voc;
         int maxcols = std::max(wcols, 2 * H);
@@ -880,18 +926,34 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         jobs.n = nj;
         for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += (jobs.job[k].ncols + 15) / 16; }
         map.seg[8] = nb;
-        DISPATCH_MT(d.MT, GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
+        if (d.MT > 4) {
+            // wide path: the products and the ready reduce jobs as two launches
+            if (int rc2 = launch_tn<0>(H, pr, 4, std::max(W.lw.S_e, W.lw.S_n), st)) return rc2;
+            if (nj > 0) {
+                int maxcols = 0;
+                for (int k = 0; k < nj; ++k) maxcols = std::max(maxcols, jobs.job[k].ncols);
+                GCN_PROF_PRE("k_reduce_slabs(layer)");
+                k_reduce_slabs<<<dim3((maxcols + 15) / 16, nj, 1), GCN_BLOCK, 0, st>>>(jobs);
+                GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
+            }
+        } else {
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
+        }
     }
     // embeddings
     GCN_PROF_PRE("k_embed_bwd_edges");
-    DISPATCH_MT(d.MT, (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
+    if (d.MT > 4)
+        k_colsum_w<false><<<W.emb_blk, 256, 0, st>>>(d.Re, H, d.C, W.de, nullptr, nullptr, nullptr, nullptr, nullptr, cap, W.embpart,
+                                                     nullptr, 0, 0.f, 0);
+    else
+        DISPATCH_MT(d.MT, if constexpr (MT != 0) (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
     GCN_CHECK_LAUNCH("k_embed_bwd_edges");
     {
         // one reduce launch: products of layer 0 (slab set 0) and the edge-embedding gradient
         ReduceJobs jobs = {};
         jobs.n = 3;
         layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);
-        jobs.job[2].partial = W.embpart; jobs.job[2].nP = W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[2].ncols = H;
+        jobs.job[2].partial = W.embpart; jobs.job[2].nP = d.MT > 4 ? W.emb_blk : W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[2].ncols = H;
         jobs.job[2].rd.n = 1; jobs.job[2].rd.dst[0] = G[2]; jobs.job[2].rd.off[0] = 0; jobs.job[2].rd.off[1] = H;
         GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");
         k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 3, 1), GCN_BLOCK, 0, st>>>(jobs);

@@ -1,0 +1,927 @@
+// Layer and head kernels for hidden sizes above 64 (up to GCN_WIDE_MAX_H): the same two-phase structure as
+// kernels_strip.hpp with 256-thread workgroups, but
+//   * phase A: thread (arow, g0) walks the float4 column groups g0, g0 + 16, ... of its row,
+//   * phase B: wavefront w walks the 16-column blocks w, w + 4, ... of the output,
+//   * the H x H weights do not fit in registers or LDS: each 16-row tile streams the weight rows of its
+//     column block from memory (L2-resident) as MFMA A operands.
+// One LDS tile per operand (single buffered, two barriers per step).  These kernels favour coverage of
+// any H over speed; the math of each is stated above its argument block in kernels_fused.hpp.
+#pragma once
+#include "common.hpp"
+#include "kernels_fused.hpp"
+#include "kernels_bwd.hpp"
+#include "kernels_strip.hpp"
+
+constexpr int GCN_WIDE_MAX_H = 320;
+constexpr int WNB = GCN_WIDE_MAX_H / 16;       // column blocks
+constexpr int WLS = GCN_WIDE_MAX_H + 4;        // LDS row stride (floats)
+constexpr int WKA = GCN_WIDE_MAX_H / 64;       // column groups per phase-A thread
+constexpr int WKB = (WNB + 3) / 4;             // column blocks per wavefront
+
+struct WideIdx {
+    int t, lane, rs, q, w, arow, g0;
+};
+__device__ __forceinline__ WideIdx wide_idx() {
+    WideIdx x;
+    x.t = threadIdx.x; x.lane = x.t & 63; x.rs = x.lane & 15; x.q = x.lane >> 4; x.w = x.t >> 6;
+    x.arow = x.t >> 4; x.g0 = x.t & 15;
+    return x;
+}
+
+// Output columns 16 nb + 4 q .. + 3 of row rs of tile * W^T, W row-major [H][H] behind descriptor rW.
+__device__ __forceinline__ f32x4 wide_gemm(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q) {
+    f32x4 acc0 = f4zero(), acc1 = f4zero();
+    const int n = 16 * nb + rs;
+    const uint32_t rowoff = n < H ? (uint32_t)n * (uint32_t)H * 4u : kOob;
+    for (int s0 = 0; s0 < NB; s0 += 4) {
+        f32x4 wf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 16 * (s0 + u) + 4 * q;
+            wf[u] = bld4(rW, (s0 + u < NB && k < H && n < H) ? rowoff + (uint32_t)k * 4u : kOob);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u < NB) {
+                const f32x4 in = ld4(&tile[rs][16 * (s0 + u) + 4 * q]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in[3], acc1, 0, 0, 0);
+            }
+        }
+    }
+    return acc0 + acc1;
+}
+
+__device__ __forceinline__ f32x4 bn_relu_res4(const f32x4 tp, const f32x4 rin, const float* mu, const float* rsd,
+                                              const float* ga, const float* be) {
+    const f32x4 pm = ld4(mu), pr = ld4(rsd), pg = ld4(ga), pb = ld4(be);
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float bn = (tp[k] - pm[k]) * pr[k] * pg[k] + pb[k];
+        v[k] = (bn > 0.f ? bn : 0.f) + rin[k];
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node forward (NodeFwdArgs): one workgroup per 16-row tile, grid-stride.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_fwd_w(NodeFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[4][GCN_WIDE_MAX_H];
+    const WideIdx ix = wide_idx();
+    const int H = a.H, NB = (H + 15) / 16, HP = 16 * NB;
+    clds_fill(cl[0], a.apply ? a.pmean : nullptr, H, HP); clds_fill(cl[1], a.apply ? a.prstd : nullptr, H, HP);
+    clds_fill(cl[2], a.apply ? a.pgamma : nullptr, H, HP); clds_fill(cl[3], a.apply ? a.pbeta : nullptr, H, HP);
+    const DropCfg dc = drop_cfg(a.rng, a.drop_sid, a.drop_p, a.drop_on && a.apply);
+    rsrc_t rW[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rW[k] = make_rsrc(a.W[k], (uint32_t)H * H * 4);
+    const int ntiles = (a.rows + 15) / 16;
+    __syncthreads();
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int row = tl * 16 + ix.arow;
+        for (int g = ix.g0; g < HP / 4; g += 16) {
+            const int acol = 4 * g;
+            f32x4 val = f4zero();
+            if (row < a.rows && acol < H) {
+                const size_t off = (size_t)row * H + acol;
+                if (!a.apply) {
+                    val = ld4(a.x_in + off);
+                } else {
+                    val = bn_relu_res4(ld4(a.prev_tmp + off), ld4(a.prev_in + off), &cl[0][acol], &cl[1][acol], &cl[2][acol], &cl[3][acol]);
+                    if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), g);
+                    if (a.x_out != nullptr) st4(a.x_out + off, val);
+                }
+            }
+            st4(&tile[ix.arow][acol], val);
+        }
+        __syncthreads();
+        const int rowb = tl * 16 + ix.rs;
+        for (int nb = ix.w; nb < NB; nb += 4) {
+            const int bcol = 16 * nb + 4 * ix.q;
+            const bool valid = rowb < a.rows && bcol < H;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                f32x4 o = wide_gemm(tile, rW[k], H, NB, nb, ix.rs, ix.q);
+                if (valid) st4(a.y[k] + (size_t)rowb * H + bcol, o + ld4(a.bias[k] + bcol));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles.
+// partial layout [gridDim.x][4][H].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_fwd_w(EdgeFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    const WideIdx ix = wide_idx();
+    const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB;
+    const EdgeSrc& S = a.src;
+    clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
+    clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
+    clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
+    const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
+    const rsrc_t rW = make_rsrc(a.WU, (uint32_t)H * H * 4);
+    f32x4 s1[WKB], s2[WKB], px1[WKB], px2[WKB];
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) { s1[k] = f4zero(); s2[k] = f4zero(); px1[k] = f4zero(); px2[k] = f4zero(); }
+    const int units = a.B * V * C;
+    const int njt = (V + 15) / 16;
+    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int bi = u / C, c = u - bi * C, b = bi / V;
+        f32x4 num[WKB], den[WKB];
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
+        for (int jt = 0; jt < njt; ++jt) {
+            {   // ---- phase A
+                const int j = jt * 16 + ix.arow;
+                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
+                const float capv = (S.mode == 2 && j < V) ? S.cap[(size_t)bi * V + j] : 0.f;
+                for (int g = ix.g0; g < HP / 4; g += 16) {
+                    const int acol = 4 * g;
+                    f32x4 val = f4zero();
+                    if (j < V && acol < H) {
+                        const size_t off = erow * H + acol;
+                        if (S.mode == 0) val = ld4(S.e_in + off);
+                        else if (S.mode == 2) val = ld4(&cl[CL_WE][acol]) * capv;
+                        else {
+                            val = bn_relu_res4(ld4(S.prev_tmp + off), ld4(S.prev_in + off), &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol],
+                                               &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
+                            if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)erow), g);
+                        }
+                        if (S.mode != 0 && S.e_out != nullptr) st4(S.e_out + off, val);
+                    }
+                    st4(&tile[ix.arow][acol], val);
+                }
+            }
+            __syncthreads();
+            {   // ---- phase B
+                const int j = jt * 16 + ix.rs;
+                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
+                const size_t nrow_j = (size_t)(b * V + min(j, V - 1)) * C + c;
+#pragma unroll
+                for (int k = 0; k < WKB; ++k) {
+                    const int nb = ix.w + 4 * k;
+                    if (nb < NB) {
+                        const int bcol = 16 * nb + 4 * ix.q;
+                        const bool valid = j < V && bcol < H;
+                        f32x4 et = wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q);
+                        if (valid) {
+                            et += (ld4(a.Ve + (size_t)u * H + bcol) + ld4(a.bU + bcol)) + ld4(a.Ve + nrow_j * H + bcol);
+                            const f32x4 vnj = ld4(a.Vn + nrow_j * H + bcol);
+                            st4(a.e_tmp + erow * H + bcol, et);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float g = sigmoidf_(et[r]);
+                                num[k][r] += g * vnj[r];
+                                den[k][r] += g;
+                                s1[k][r] += et[r];
+                                s2[k][r] += et[r] * et[r];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- unit end
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const f32x4 nm = red16x4(num[k]), dn = red16x4(den[k]);
+                if (ix.rs == 0 && bcol < H) {
+                    f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
+                    if (a.mean_agg) {
+                        D = dn + 1e-20f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) A[r] = nm[r] * __builtin_amdgcn_rcpf(D[r]);
+                    }
+                    const f32x4 xt = ld4(a.Ux + (size_t)u * H + bcol) + A;
+                    st4(a.x_tmp + (size_t)u * H + bcol, xt);
+                    st4(a.Aout + (size_t)u * H + bcol, A);
+                    st4(a.Dout + (size_t)u * H + bcol, D);
+                    px1[k] += xt; px2[k] += xt * xt;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) {
+        const int nb = ix.w + 4 * k;
+        if (nb < NB) {
+            const int bcol = 16 * nb + 4 * ix.q;
+            const f32x4 t1 = red16x4(s1[k]), t2 = red16x4(s2[k]);
+            if (ix.rs == 0 && bcol < H) {
+                float* p = a.partial + (size_t)blockIdx.x * 4 * H;
+                st4(p + bcol, t1); st4(p + H + bcol, t2); st4(p + 2 * H + bcol, px1[k]); st4(p + 3 * H + bcol, px2[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_bwd_w(EdgeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tdet[16][WLS];
+    __shared__ __attribute__((aligned(16))) float tpre[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cc[16][GCN_WIDE_MAX_H];   // 0..5 edge BN, 6..11 node BN, 12..15 layer below
+    const WideIdx ix = wide_idx();
+    const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB;
+    const bool do_next = a.next.tmp != nullptr;
+    const bool mean_agg = a.mean_agg != 0;
+    clds_fill(cc[0], a.stats, H, HP); clds_fill(cc[1], a.stats + H, H, HP);
+    clds_fill(cc[2], a.gamma_e, H, HP); clds_fill(cc[3], a.beta_e, H, HP);
+    clds_fill(cc[4], a.bstats_e, H, HP); clds_fill(cc[5], a.bstats_e + H, H, HP);
+    clds_fill(cc[6], a.stats + 2 * H, H, HP); clds_fill(cc[7], a.stats + 3 * H, H, HP);
+    clds_fill(cc[8], a.gamma_x, H, HP); clds_fill(cc[9], a.beta_x, H, HP);
+    clds_fill(cc[10], a.bstats_x, H, HP); clds_fill(cc[11], a.bstats_x + H, H, HP);
+    clds_fill(cc[12], do_next ? a.next.mean : nullptr, H, HP); clds_fill(cc[13], do_next ? a.next.rstd : nullptr, H, HP);
+    clds_fill(cc[14], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(cc[15], do_next ? a.next.beta : nullptr, H, HP);
+    const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    const rsrc_t rW = make_rsrc(a.WUt, (uint32_t)H * H * 4);
+    f32x4 na1[WKB], na2[WKB];
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) { na1[k] = f4zero(); na2[k] = f4zero(); }
+    const int njt = (V + 15) / 16;
+    const int nit = (V + IT - 1) / IT;
+    const int units = a.B * nit * njt * C;
+    const size_t Rn = (size_t)a.B * V * C;
+    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        int tt = u;
+        const int c = tt % C; tt /= C;
+        const int jt = tt % njt; tt /= njt;
+        const int it = tt % nit;
+        const int b = tt / nit;
+        const int ja = jt * 16 + ix.arow;
+        const size_t nrow_ja = (size_t)(b * V + min(ja, V - 1)) * C + c;
+        f32x4 cve[WKA], cvn[WKA];
+#pragma unroll
+        for (int k = 0; k < WKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
+        const int i_end = min(V, (it + 1) * IT);
+        for (int i = it * IT; i < i_end; ++i) {
+            const size_t nrow_i = (size_t)(b * V + i) * C + c;
+            {   // ---- phase A
+                const size_t erow = ((size_t)(b * V + i) * V + min(ja, V - 1)) * C + c;
+                const uint32_t rhx = dcx.on ? drop_rowhash(dcx, (uint32_t)nrow_i) : 0u;
+                const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
+#pragma unroll
+                for (int k = 0; k < WKA; ++k) {
+                    const int g = ix.g0 + 16 * k;
+                    const int acol = 4 * g;
+                    if (acol < HP) {
+                        f32x4 det = f4zero(), dpre = f4zero();
+                        if (ja < V && acol < H) {
+                            const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
+                            f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f}, ai = f4zero();
+                            if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
+                            const f32x4 dn = ld4(a.de + erow * H + acol), tp = ld4(a.e_tmp + erow * H + acol);
+                            const f32x4 vnj = ld4(a.Vn + nrow_ja * H + acol);
+                            f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f}, dme = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (dcx.on) { dmx = drop_mul4(dcx, rhx, g); dme = drop_mul4(dce, rhe, g); }
+                            const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
+                            const f32x4 ebe = ld4(&cc[3][acol]), em1 = ld4(&cc[4][acol]), em2 = ld4(&cc[5][acol]);
+                            const f32x4 xmu = ld4(&cc[6][acol]), xrs = ld4(&cc[7][acol]), xga = ld4(&cc[8][acol]);
+                            const f32x4 xbe = ld4(&cc[9][acol]), xm1 = ld4(&cc[10][acol]), xm2 = ld4(&cc[11][acol]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float xhx = (xt[r] - xmu[r]) * xrs[r];
+                                const float bnx = xhx * xga[r] + xbe[r];
+                                const float dxd = dxn[r] * dmx[r];
+                                const float dbnx = bnx > 0.f ? dxd : 0.f;
+                                const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
+                                const float qi = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[r]) : dxt;
+                                const float x = tp[r];
+                                const float xh = (x - emu[r]) * ers[r];
+                                const float bn = xh * ega[r] + ebe[r];
+                                const float d = dn[r] * dme[r];
+                                const float dbn = bn > 0.f ? d : 0.f;
+                                const float gt = sigmoidf_(x);
+                                const float v = ega[r] * ers[r] * (dbn - em1[r] - xh * em2[r]) + qi * (vnj[r] - ai[r]) * gt * (1.f - gt);
+                                det[r] = v;
+                                dpre[r] = d;
+                                cve[k][r] += v;
+                                cvn[k][r] += qi * gt;
+                            }
+                            st4(a.det_out + erow * H + acol, det);
+                        }
+                        st4(&tdet[ix.arow][acol], det);
+                        st4(&tpre[ix.arow][acol], dpre);
+                    }
+                }
+            }
+            __syncthreads();
+            {   // ---- phase B
+                const int jb = jt * 16 + ix.rs;
+                const size_t erow_b = ((size_t)(b * V + i) * V + min(jb, V - 1)) * C + c;
+                const uint32_t rhn = ndc.on ? drop_rowhash(ndc, (uint32_t)erow_b) : 0u;
+#pragma unroll
+                for (int k = 0; k < WKB; ++k) {
+                    const int nb = ix.w + 4 * k;
+                    if (nb < NB) {
+                        const int bcol = 16 * nb + 4 * ix.q;
+                        const bool valid_b = jb < V && bcol < H;
+                        const f32x4 din = wide_gemm(tdet, rW, H, NB, nb, ix.rs, ix.q) + ld4(&tpre[ix.rs][bcol]);
+                        f32x4 rsum = ld4(&tdet[ix.rs][bcol]);
+                        if (valid_b) {
+                            st4(a.de + erow_b * H + bcol, din);
+                            if (do_next) {
+                                const f32x4 ntp = ld4(a.next.tmp + erow_b * H + bcol);
+                                const f32x4 nmu = ld4(&cc[12][bcol]), nrs = ld4(&cc[13][bcol]), nga = ld4(&cc[14][bcol]), nbe = ld4(&cc[15][bcol]);
+                                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                                if (ndc.on) dm = drop_mul4(ndc, rhn, bcol >> 2);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                                    const float bn = xh * nga[r] + nbe[r];
+                                    const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
+                                    na1[k][r] += d;
+                                    na2[k][r] += d * xh;
+                                }
+                            }
+                        }
+                        rsum = red16x4(rsum);
+                        if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i) * H + bcol, rsum);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (ja < V) {
+#pragma unroll
+            for (int k = 0; k < WKA; ++k) {
+                const int acol = 4 * (ix.g0 + 16 * k);
+                if (acol < H) {
+                    st4(a.colVe + ((size_t)it * Rn + nrow_ja) * H + acol, cve[k]);
+                    st4(a.colVn + ((size_t)it * Rn + nrow_ja) * H + acol, cvn[k]);
+                }
+            }
+        }
+    }
+    if (do_next) {
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const f32x4 t1 = red16x4(na1[k]), t2 = red16x4(na2[k]);
+                if (ix.rs == 0 && bcol < H) {
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, t1);
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, t2);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node backward (NodeBwdArgs): one workgroup per 16-row tile (every workgroup of the grid writes a partial row).
+// The three products share one LDS tile, filled three times.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_bwd_w(NodeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cc[10][GCN_WIDE_MAX_H];   // 0..5 this BN, 6..9 layer below
+    const WideIdx ix = wide_idx();
+    const int H = a.H, NB = (H + 15) / 16, HP = 16 * NB;
+    const bool do_next = a.next.tmp != nullptr;
+    clds_fill(cc[0], a.mean, H, HP); clds_fill(cc[1], a.rstd, H, HP); clds_fill(cc[2], a.gamma, H, HP);
+    clds_fill(cc[3], a.beta, H, HP); clds_fill(cc[4], a.bstats, H, HP); clds_fill(cc[5], a.bstats + H, H, HP);
+    clds_fill(cc[6], do_next ? a.next.mean : nullptr, H, HP); clds_fill(cc[7], do_next ? a.next.rstd : nullptr, H, HP);
+    clds_fill(cc[8], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(cc[9], do_next ? a.next.beta : nullptr, H, HP);
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    const rsrc_t rWu = make_rsrc(a.WnUt, (uint32_t)H * H * 4), rWn = make_rsrc(a.WnVt, (uint32_t)H * H * 4),
+                 rWe = make_rsrc(a.WeVt, (uint32_t)H * H * 4);
+    f32x4 na1[WKB], na2[WKB];
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) { na1[k] = f4zero(); na2[k] = f4zero(); }
+    const int ntiles = (a.rows + 15) / 16;
+    __syncthreads();
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int rowa = tl * 16 + ix.arow;
+        const int rowb = tl * 16 + ix.rs;
+        f32x4 acc[WKB];
+        // pass 0: dUx = dx_tmp, pass 1: dVn, pass 2: dVe
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int g = ix.g0; g < HP / 4; g += 16) {
+                const int acol = 4 * g;
+                f32x4 v = f4zero();
+                if (rowa < a.rows && acol < H) {
+                    const size_t off = (size_t)rowa * H + acol;
+                    if (pass == 0) {
+                        const f32x4 dxo = ld4(a.dx + off), xt = ld4(a.x_tmp + off);
+                        f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (dcx.on) dm = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)rowa), g);
+                        const f32x4 mu = ld4(&cc[0][acol]), rsd = ld4(&cc[1][acol]), ga = ld4(&cc[2][acol]), be = ld4(&cc[3][acol]);
+                        const f32x4 m1 = ld4(&cc[4][acol]), m2 = ld4(&cc[5][acol]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (xt[r] - mu[r]) * rsd[r];
+                            const float bn = xh * ga[r] + be[r];
+                            const float d = dxo[r] * dm[r];
+                            const float dbn = bn > 0.f ? d : 0.f;
+                            v[r] = ga[r] * rsd[r] * (dbn - m1[r] - xh * m2[r]);
+                        }
+                        st4(a.dxtmp_out + off, v);
+                    } else if (pass == 1) {
+                        for (int k = 0; k < a.nit; ++k) v += ld4(a.colVn + (size_t)k * a.rows * H + off);
+                        st4(a.dVn_out + off, v);
+                    } else {
+                        for (int k = 0; k < a.nit; ++k) v += ld4(a.colVe + (size_t)k * a.rows * H + off);
+                        for (int k = 0; k < a.njt; ++k) v += ld4(a.rowpart + (size_t)k * a.rows * H + off);
+                        st4(a.dVe_out + off, v);
+                    }
+                }
+                st4(&tile[ix.arow][acol], v);
+            }
+            __syncthreads();
+            const rsrc_t rW = pass == 0 ? rWu : (pass == 1 ? rWn : rWe);
+#pragma unroll
+            for (int k = 0; k < WKB; ++k) {
+                const int nb = ix.w + 4 * k;
+                if (nb < NB) {
+                    const f32x4 o = wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q);
+                    acc[k] = pass == 0 ? o : acc[k] + o;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (nb < NB && rowb < a.rows && bcol < H) {
+                const size_t off = (size_t)rowb * H + bcol;
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (dcx.on) dm = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)rowb), bcol >> 2);
+                const f32x4 res = acc[k] + ld4(a.dx + off) * dm;       // + dpre (residual branch)
+                st4(a.dx + off, res);
+                if (do_next) {
+                    const f32x4 ntp = ld4(a.next.tmp + off);
+                    const f32x4 nmu = ld4(&cc[6][bcol]), nrs = ld4(&cc[7][bcol]), nga = ld4(&cc[8][bcol]), nbe = ld4(&cc[9][bcol]);
+                    f32x4 ndm = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (ndc.on) ndm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)rowb), bcol >> 2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                        const float bn = xh * nga[r] + nbe[r];
+                        const float d = bn > 0.f ? res[r] * ndm[r] : 0.f;
+                        na1[k][r] += d;
+                        na2[k][r] += d * xh;
+                    }
+                }
+            }
+        }
+        __syncthreads();      // the in-place dx rows of this tile are complete before another pass 0 could read them
+    }
+    if (do_next) {
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const f32x4 t1 = red16x4(na1[k]), t2 = red16x4(na2[k]);
+                if (ix.rs == 0 && bcol < H) {
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, t1);
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, t2);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient products (TnProblems, slab layout as k_gemm_tn2): grid (slices, column-block quads, problems);
+// wavefront w of workgroup (slice, y, prob) accumulates dW rows 16 (4 y + w) .. + 15.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_tn_w(int H, TnProblems pr) {
+    constexpr int LT = GCN_WIDE_MAX_H + 16;
+    __shared__ __attribute__((aligned(16))) float tx[16][64 + 16];
+    __shared__ __attribute__((aligned(16))) float ty[16][LT];
+    const WideIdx ix = wide_idx();
+    const int NB = (H + 15) / 16, HP = 16 * NB;
+    const int prob = blockIdx.z, slice = blockIdx.x, nslices = pr.nslices[prob];
+    if (slice >= nslices) return;
+    const int nb = 4 * (int)blockIdx.y + ix.w;                 // this wavefront's block of dW rows
+    const size_t rows = pr.rows[prob];
+    const float* __restrict__ X = pr.X[prob];
+    const float* __restrict__ Y = pr.Y[prob];
+    const size_t ntiles = (rows + 15) / 16;
+    const size_t per = (ntiles + nslices - 1) / nslices;
+    const size_t t0 = (size_t)slice * per, t1 = min(ntiles, t0 + per);
+    f32x4 acc[WNB];
+#pragma unroll
+    for (int k = 0; k < WNB; ++k) acc[k] = f4zero();
+    float bsum = 0.f;
+    for (size_t tile = t0; tile < t1; ++tile) {
+        const size_t row = tile * 16 + ix.arow;
+        {   // X columns 64 y .. 64 y + 63 of the tile, all Y columns
+            const int xcol = 64 * (int)blockIdx.y + 4 * ix.g0;
+            st4(&tx[ix.arow][4 * ix.g0], (row < rows && xcol < H) ? ld4(X + row * H + xcol) : f4zero());
+            for (int g = ix.g0; g < HP / 4; g += 16) {
+                const int acol = 4 * g;
+                st4(&ty[ix.arow][acol], (row < rows && acol < H) ? ld4(Y + row * H + acol) : f4zero());
+            }
+        }
+        __syncthreads();
+        if (nb < NB) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float av = tx[4 * st + ix.q][16 * ix.w + ix.rs];
+                bsum += av;
+#pragma unroll
+                for (int k = 0; k < WNB; ++k)
+                    if (k < NB) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ty[4 * st + ix.q][16 * k + ix.rs], acc[k], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (nb >= NB) return;
+    float* out = pr.out[prob] + (size_t)slice * pr.out_stride[prob];
+#pragma unroll
+    for (int k = 0; k < WNB; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = 16 * nb + 4 * ix.q + r, kc = 16 * k + ix.rs;
+            if (k < NB && nn < H && kc < H) out[(size_t)nn * H + kc] = acc[k][r];
+        }
+    bsum = redq(bsum);
+    const int n = 16 * nb + ix.rs;
+    if (ix.q == 0 && n < H) out[(size_t)H * H + n] = bsum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head (edge MLP with at most one hidden layer, loss, edge error), forward.  Same outputs as k_head_fwd;
+// loss_partial has one row per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct HeadRowLogits {
+    float l0, l1;
+};
+// Sum over the workgroup of per-lane partial dot products of one row (lane (rs, q) of every wavefront holds a part
+// of row rs): returns the totals of row rs to every lane.  red: [4 waves][16 rows][2].
+__device__ __forceinline__ HeadRowLogits head_row_sum(float p0, float p1, float (*red)[16][2], const WideIdx& ix) {
+    p0 = redq(p0); p1 = redq(p1);
+    if (ix.q == 0) { red[ix.w][ix.rs][0] = p0; red[ix.w][ix.rs][1] = p1; }
+    __syncthreads();
+    HeadRowLogits o;
+    o.l0 = red[0][ix.rs][0] + red[1][ix.rs][0] + red[2][ix.rs][0] + red[3][ix.rs][0];
+    o.l1 = red[0][ix.rs][1] + red[1][ix.rs][1] + red[2][ix.rs][1] + red[3][ix.rs][1];
+    __syncthreads();
+    return o;
+}
+
+// phase A of both head kernels: the head's input tile from EdgeSrc into LDS (and optionally to e_stash)
+__device__ __forceinline__ void head_src_tile(float (*tile)[WLS], const EdgeSrc& S, const float (*cl)[GCN_WIDE_MAX_H],
+                                              const DropCfg& dc, size_t tile0, size_t rows, int H, int HP, int C,
+                                              float* e_stash, const WideIdx& ix) {
+    const size_t row = tile0 + ix.arow;
+    const float capv = (S.mode == 2 && row < rows) ? S.cap[row / C] : 0.f;
+    for (int g = ix.g0; g < HP / 4; g += 16) {
+        const int acol = 4 * g;
+        f32x4 val = f4zero();
+        if (row < rows && acol < H) {
+            const size_t off = row * H + acol;
+            if (S.mode == 0) val = ld4(S.e_in + off);
+            else if (S.mode == 2) val = ld4(&cl[CL_WE][acol]) * capv;
+            else {
+                val = bn_relu_res4(ld4(S.prev_tmp + off), ld4(S.prev_in + off), &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol],
+                                   &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
+                if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), g);
+            }
+            if (e_stash != nullptr) st4(e_stash + off, val);
+        }
+        st4(&tile[ix.arow][acol], val);
+    }
+}
+
+template <int NHID>
+__global__ __launch_bounds__(256) void k_head_fwd_w(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, const float* __restrict__ cap, int mask_invalid,
+    const long long* __restrict__ y_edges, const float* __restrict__ edge_cw, float* __restrict__ logits,
+    float* __restrict__ loss_partial, int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0,
+    float p, int training) {
+    static_assert(NHID <= 1, "the wide head supports at most one hidden layer");
+    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    __shared__ float red[4][16][2];
+    const WideIdx ix = wide_idx();
+    const int NB = (H + 15) / 16, HP = 16 * NB;
+    clds_fill(cl[CL_PMEAN], src.mode == 1 ? src.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], src.mode == 1 ? src.prstd : nullptr, H, HP);
+    clds_fill(cl[CL_PGAMMA], src.mode == 1 ? src.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], src.mode == 1 ? src.pbeta : nullptr, H, HP);
+    clds_fill(cl[CL_WE], src.mode == 2 ? src.we : nullptr, H, HP);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
+    const rsrc_t rW = make_rsrc(NHID ? hp.hidW[0] : hp.outW, (uint32_t)H * H * 4);
+    const size_t ntiles = (rows + 15) / 16;
+    const int BC_stride = V * V * C;
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    float acc_wn = 0.f, acc_w = 0.f;
+    __syncthreads();
+    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        head_src_tile(tile, src, cl, sdc, tl * 16, rows, H, HP, C, nullptr, ix);
+        __syncthreads();
+        const size_t row = tl * 16 + ix.rs;
+        const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (nb < NB) {                                   // wavefront-uniform: every lane takes part in the MFMAs
+                f32x4 h = NHID ? wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q) : ld4(&tile[ix.rs][bcol]);
+                if (bcol < H) {
+                    if (NHID) {
+                        h += ld4(hp.hidB[0] + bcol);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = h[r] > 0.f ? h[r] : 0.f;
+                        if (hdc.on) h *= drop_mul4(hdc, rh, bcol >> 2);
+                    }
+                    const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { p0 += h[r] * w0[r]; p1 += h[r] * w1[r]; }
+                }
+            }
+        }
+        const HeadRowLogits lg = head_row_sum(p0, p1, red, ix);
+        float l0 = lg.l0 + b2_0, l1 = lg.l1 + b2_1;
+        if (row < rows && ix.w == 0 && ix.q == 0) {
+            if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+            if (voc == 1) {
+                logits[row] = l0;
+            } else {
+                logits[row * 2] = l0;
+                logits[row * 2 + 1] = l1;
+                if (y_edges != nullptr) {
+                    const int y = (int)y_edges[row];
+                    const float mx = fmaxf(l0, l1);
+                    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+                    const float w = y ? cw1 : cw0;
+                    acc_wn += -w * ((y ? l1 : l0) - lse);
+                    acc_w += w;
+                    const int pred = l1 > l0 ? 1 : 0;
+                    if (y + pred > 0) {
+                        const int b = (int)(row / BC_stride), c = (int)(row % C);
+                        const int BC = (int)(rows / BC_stride) * C;
+                        atomicAdd(&counts[BC + b * C + c], 1);
+                        if (pred == y) atomicAdd(&counts[b * C + c], 1);
+                    }
+                }
+            }
+        }
+    }
+    if (loss_partial != nullptr && ix.w == 0) {
+        acc_wn = red16(acc_wn);
+        acc_w = red16(acc_w);
+        if (ix.t == 0) {
+            loss_partial[(size_t)blockIdx.x * 2] = acc_wn;
+            loss_partial[(size_t)blockIdx.x * 2 + 1] = acc_w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head backward (same outputs as k_head_bwd, NHID <= 1).  wpartial has one row per workgroup:
+// [voc][H] output-layer weight gradient followed by voc bias gradients, row stride (voc*H + voc + 3) & ~3.
+// hidWt: the transposed hidden weight (needed only with NHID = 1).
+// ------------------------------------------------------------------------------------------------
+template <int NHID>
+__global__ __launch_bounds__(256) void k_head_bwd_w(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ hidWt, EdgeSrc src, NextBn next,
+    float* __restrict__ e_stash, const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
+    const float* __restrict__ edge_cw, const float* __restrict__ loss_out, const float* __restrict__ dloss,
+    const float* __restrict__ dy_pred, float* __restrict__ de, float* __restrict__ dpre_stash,
+    float* __restrict__ wpartial, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z) {
+    static_assert(NHID <= 1, "the wide head supports at most one hidden layer");
+    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float tdp[16][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    __shared__ float red[4][16][2];
+    zero_fill(z);
+    const WideIdx ix = wide_idx();
+    const int NB = (H + 15) / 16, HP = 16 * NB;
+    clds_fill(cl[CL_PMEAN], src.mode == 1 ? src.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], src.mode == 1 ? src.prstd : nullptr, H, HP);
+    clds_fill(cl[CL_PGAMMA], src.mode == 1 ? src.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], src.mode == 1 ? src.pbeta : nullptr, H, HP);
+    clds_fill(cl[CL_WE], src.mode == 2 ? src.we : nullptr, H, HP);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
+    const bool do_next = next.tmp != nullptr;
+    const rsrc_t rW = make_rsrc(NHID ? hp.hidW[0] : hp.outW, (uint32_t)H * H * 4);
+    const rsrc_t rWt = make_rsrc(NHID ? hidWt : hp.outW, (uint32_t)H * H * 4);
+    const size_t ntiles = (rows + 15) / 16;
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    const bool has_loss = (y_edges != nullptr) && voc == 2;
+    const float gl = has_loss ? (dloss ? dloss[0] : 1.f) / loss_out[1] : 0.f;
+    f32x4 gw0[WKB], gw1[WKB], na1[WKB], na2[WKB];
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) { gw0[k] = f4zero(); gw1[k] = f4zero(); na1[k] = f4zero(); na2[k] = f4zero(); }
+    float gb0 = 0.f, gb1 = 0.f;
+    __syncthreads();
+    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        head_src_tile(tile, src, cl, sdc, tl * 16, rows, H, HP, C, e_stash, ix);
+        __syncthreads();
+        const size_t row = tl * 16 + ix.rs;
+        const bool rvalid = row < rows;
+        const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
+        f32x4 h[WKB], dmul[WKB];
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            h[k] = f4zero(); dmul[k] = f4zero();
+            if (nb < NB) {
+                f32x4 pre = NHID ? wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q) : f4zero();
+                if (bcol < H) {
+                    if (NHID) {
+                        pre += ld4(hp.hidB[0] + bcol);
+                        f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (hdc.on) dm = drop_mul4(hdc, rh, bcol >> 2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dmul[k][r] = pre[r] > 0.f ? dm[r] : 0.f;
+                            h[k][r] = (pre[r] > 0.f ? pre[r] : 0.f) * dm[r];
+                        }
+                    } else {
+                        h[k] = ld4(&tile[ix.rs][bcol]);
+                        dmul[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    }
+                    const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { p0 += h[k][r] * w0[r]; p1 += h[k][r] * w1[r]; }
+                }
+            }
+        }
+        const HeadRowLogits lg = head_row_sum(p0, p1, red, ix);
+        // d logits of this lane's row (every lane of the row computes the same two values)
+        float d0 = 0.f, d1 = 0.f;
+        if (rvalid) {
+            const bool masked = mask_invalid && cap[row / C] == 0.f;
+            if (!masked) {
+                if (voc == 1) {
+                    d0 = dy_pred ? dy_pred[row] : 0.f;
+                } else {
+                    if (has_loss) {
+                        const float l0 = lg.l0 + b2_0, l1 = lg.l1 + b2_1;
+                        const int y = (int)y_edges[row];
+                        const float mx = fmaxf(l0, l1);
+                        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
+                        const float w = (y ? cw1 : cw0) * gl;
+                        d0 = w * (e0 * inv - (y == 0 ? 1.f : 0.f));
+                        d1 = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
+                    }
+                    if (dy_pred) { d0 += dy_pred[row * 2]; d1 += dy_pred[row * 2 + 1]; }
+                }
+            }
+        }
+        if (ix.w == 0 && ix.q == 0) { gb0 += d0; gb1 += d1; }
+        // output layer backward: d outW += d logit x h ; dh = d0 w0 + d1 w1 ; dpre = dh * relu' * dropout
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (nb < NB) {
+                f32x4 dp = f4zero();
+                if (bcol < H) {
+                    const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gw0[k][r] += d0 * h[k][r];
+                        gw1[k][r] += d1 * h[k][r];
+                        dp[r] = (d0 * w0[r] + d1 * w1[r]) * dmul[k][r];
+                    }
+                    if (NHID && rvalid) st4(dpre_stash + row * H + bcol, dp);
+                }
+                st4(&tdp[ix.rs][16 * nb + 4 * ix.q], dp);
+            }
+        }
+        __syncthreads();
+        // hidden layer backward: de = dpre W_0 (or dpre itself without a hidden layer); statistics of the last conv layer
+        const uint32_t nrh = (do_next && sdc.on) ? drop_rowhash(sdc, (uint32_t)row) : 0u;
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (nb < NB) {
+                const f32x4 dv = NHID ? wide_gemm(tdp, rWt, H, NB, nb, ix.rs, ix.q) : ld4(&tdp[ix.rs][bcol]);
+                if (rvalid && bcol < H) {
+                    st4(de + row * H + bcol, dv);
+                    if (do_next) {
+                        const f32x4 ntp = ld4(next.tmp + row * H + bcol);
+                        const f32x4 nmu = ld4(&cl[CL_PMEAN][bcol]), nrs = ld4(&cl[CL_PRSTD][bcol]);
+                        const f32x4 nga = ld4(&cl[CL_PGAMMA][bcol]), nbe = ld4(&cl[CL_PBETA][bcol]);
+                        f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                        if (sdc.on) dm = drop_mul4(sdc, nrh, bcol >> 2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                            const float bn = xh * nga[r] + nbe[r];
+                            const float d = bn > 0.f ? dv[r] * dm[r] : 0.f;
+                            na1[k][r] += d;
+                            na2[k][r] += d * xh;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int wstride = (voc * H + voc + 3) & ~3;
+    float* wp = wpartial + (size_t)blockIdx.x * wstride;
+#pragma unroll
+    for (int k = 0; k < WKB; ++k) {
+        const int nb = ix.w + 4 * k;
+        const int bcol = 16 * nb + 4 * ix.q;
+        if (nb < NB) {
+            const f32x4 g0 = red16x4(gw0[k]), g1 = red16x4(gw1[k]);
+            const f32x4 t1 = red16x4(na1[k]), t2 = red16x4(na2[k]);
+            if (ix.rs == 0 && bcol < H) {
+                st4(wp + bcol, g0);
+                if (voc > 1) st4(wp + H + bcol, g1);
+                if (do_next) {
+                    st4(next.partial + (size_t)blockIdx.x * 2 * H + bcol, t1);
+                    st4(next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, t2);
+                }
+            }
+        }
+    }
+    if (ix.w == 0) {
+        gb0 = red16(gb0); gb1 = red16(gb1);      // lanes with q != 0 hold zeros
+        if (ix.t == 0) { wp[voc * H] = gb0; if (voc > 1) wp[voc * H + 1] = gb1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-channel sums over rows for any H, one partial row per workgroup:
+//   BNSTATS: partial[block][2][H] = sum(dbn), sum(dbn * xhat) of a BatchNorm backward (as k_bn_bwd_stats)
+//   else   : partial[block][H]    = sum_row g[row][h] * scale[row / C]         (edge-embedding gradient)
+// Thread (lane r, column group g): r = t / (H/4) walks rows r, r + R, ...; lanes are combined through LDS.
+// ------------------------------------------------------------------------------------------------
+template <bool BNSTATS>
+__global__ __launch_bounds__(256) void k_colsum_w(size_t rows, int H, int C, const float* __restrict__ g, const float* __restrict__ tmp,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ scale, float* __restrict__ partial,
+                                                  const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    __shared__ __attribute__((aligned(16))) float acc[2][GCN_WIDE_MAX_H];
+    const int G = H / 4;
+    const int R = 256 / G;                       // row lanes (G <= 80)
+    const int t = threadIdx.x, r = t / G, cg = t - r * G, col = 4 * cg;
+    for (int k = t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&acc[0][0])[k] = 0.f;
+    __syncthreads();
+    const DropCfg dc = drop_cfg(rng, stream_id, p, training && BNSTATS);
+    const size_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * per, r1 = min(rows, r0 + per);
+    f32x4 a1 = f4zero(), a2 = f4zero();
+    if (r < R) {
+        f32x4 mu = f4zero(), rsd = f4zero(), ga = f4zero(), be = f4zero();
+        if (BNSTATS) { mu = ld4(mean + col); rsd = ld4(rstd + col); ga = ld4(gamma + col); be = ld4(beta + col); }
+        for (size_t row = r0 + r; row < r1; row += R) {
+            const f32x4 gv = ld4(g + row * H + col);
+            if (BNSTATS) {
+                const f32x4 tp = ld4(tmp + row * H + col);
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (dc.on) dm = drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), cg);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (tp[k] - mu[k]) * rsd[k];
+                    const float bn = xh * ga[k] + be[k];
+                    const float d = bn > 0.f ? gv[k] * dm[k] : 0.f;
+                    a1[k] += d;
+                    a2[k] += d * xh;
+                }
+            } else {
+                a1 += gv * scale[row / C];
+            }
+        }
+    }
+    // combine the row lanes in lane order (deterministic): lane r adds in turn
+    for (int rr = 0; rr < R; ++rr) {
+        if (r == rr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[0][col + k] += a1[k]; acc[1][col + k] += a2[k]; }
+        }
+        __syncthreads();
+    }
+    const int nout = BNSTATS ? 2 * H : H;
+    for (int k = t; k < nout; k += 256) partial[(size_t)blockIdx.x * nout + k] = acc[k / H][k % H];
+}

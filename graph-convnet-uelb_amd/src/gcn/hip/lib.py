@@ -15,7 +15,7 @@ import torch
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
 ABI_VERSION = 1
-MAX_H = 64
+MAX_H = 320
 LAYER_NPARAMS = 12
 
 

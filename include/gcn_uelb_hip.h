@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define GCN_ABI_VERSION 1
-#define GCN_MAX_H 64
+#define GCN_MAX_H 320
 #define GCN_LAYER_NPARAMS 12
 #define GCN_MAX_MLP_LAYERS 4
 

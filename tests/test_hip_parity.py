@@ -188,3 +188,102 @@ def test_layer_p0_train_equals_eval():
     layer.eval()
     b = layer(x, e)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ---- hidden sizes above 64 (the kernels that stream the weights instead of holding them in registers)
+WIDE_LAYER_CASES = [(2, 5, 3, 80, "mean"), (1, 18, 2, 128, "mean"), (1, 6, 2, 300, "mean"), (2, 5, 2, 72, "sum"),
+                    (1, 17, 1, 320, "mean")]
+
+
+@pytest.mark.parametrize("B,V,C,H,agg", WIDE_LAYER_CASES)
+def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
+    test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
+
+
+@pytest.mark.parametrize("H,L,mlp_layers,voc", [(80, 2, 2, 2), (128, 3, 2, 2), (300, 2, 2, 2), (96, 2, 1, 2), (72, 2, 2, 1),
+                                                 (16, 30, 2, 2), (32, 17, 3, 2)])
+def test_wide_model_matches_oracle(H, L, mlp_layers, voc):
+    """Whole model (embedding, L layers, edge MLP, loss) against the oracle in float64: hidden sizes above 64, and
+    stacks deeper than 15 layers (the 30 of the large synthetic configuration)."""
+    from src.common.synthetic import make_batch
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    dev = _dev()
+    B, V, C = 2, 7, 3
+    batch = make_batch(B, V, C, "random", 1000, 5000, 5, 500, seed=3)
+    cfg = _Cfg(num_nodes=V, num_commodities=C, voc_edges_in=3, voc_edges_out=voc, hidden_dim=H, num_layers=L,
+               mlp_layers=mlp_layers, aggregation="mean")
+    cap = torch.from_numpy(batch["edges_capacity"])
+    comm = torch.from_numpy(batch["commodities"])
+    nodes = torch.from_numpy(batch["nodes"])
+    y_edges = torch.from_numpy(batch["edges_target"])
+    cw = batch["edge_cw"]
+    ocfg = dict(num_layers=L, mlp_layers=mlp_layers, aggregation="mean", voc_edges_out=voc)
+    for attempt in range(64):          # weights without a ReLU input within float32 rounding of zero (see _relu_margin)
+        torch.manual_seed(H + L + 7919 * attempt)
+        model = ResidualGatedGCNModel(cfg, torch.float32, torch.long)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "batch_norm.weight" in n:
+                    p.add_(0.2 * torch.randn_like(p))
+                if "batch_norm.bias" in n:
+                    p.add_(0.1 * torch.randn_like(p))
+        P = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            _, _, layers = gcn_oracle.model_forward(P, ocfg, cap.double(), comm[:, :, 2].double(), nodes, compute_loss=False,
+                                                    return_layers=True)
+            margin = min(min(float(gcn_oracle.batch_norm_rows(aux[t], P[f"gcn_layers.{l}.bn_{n}.batch_norm.weight"],
+                                                              P[f"gcn_layers.{l}.bn_{n}.batch_norm.bias"]).abs().min())
+                             for t, n in (("e_tmp", "edge"), ("x_tmp", "node")))
+                         for l, (_, _, aux) in enumerate(layers))
+        # activations here reach the thousands (capacities times embedding weights), so float32 rounding of a
+        # BatchNorm output is a few 1e-6: keep every ReLU input at least 1e-5 away from zero
+        if margin > 1e-5:
+            break
+    else:
+        pytest.fail("no tie-free seed found")
+    model = model.to(dev).eval()
+    x_edges = (cap > 0).long().to(dev)
+    if voc == 2:
+        y_ref, loss_ref = gcn_oracle.model_forward(P, ocfg, cap.double(), comm[:, :, 2].double(), nodes, y_edges, cw)
+        loss_ref.backward()
+        y, loss = model(x_edges, comm.to(dev), cap.to(dev), nodes.to(dev), y_edges.to(dev), cw)
+        loss.backward()
+        assert_close(loss, loss_ref, "loss")
+    else:
+        gy = torch.randn(B, V, V, C)
+        y_ref, _ = gcn_oracle.model_forward(P, ocfg, cap.double(), comm[:, :, 2].double(), nodes, compute_loss=False,
+                                            mask_invalid_edges=True)
+        (y_ref * gy.double()).sum().backward()
+        y, loss = model(x_edges, comm.to(dev), cap.to(dev), nodes.to(dev), compute_loss=False, mask_invalid_edges=True)
+        assert loss is None
+        (y * gy.to(dev)).sum().backward()
+    assert_close(y, y_ref, "y_pred")
+    ref = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    for k, p in model.named_parameters():
+        assert_close(p.grad, ref[k], "grad " + k, atol=1e-6 * gmax)
+
+
+def test_wide_layer_train_mode_is_consistent():
+    """Dropout at H = 96: the backward pass regenerates the forward mask (gradient of sum(e_new) with respect to e is
+    zero exactly where... the residual path is dropped), and two calls draw different masks."""
+    from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
+    dev = _dev()
+    torch.manual_seed(2)
+    B, V, C, H, p = 2, 6, 3, 96, 0.3
+    layer = ResidualGatedGCNLayer(H, "mean", dropout_rate=p).to(dev).train()
+    x = (torch.randn(B, V, C, H) + 4.0).to(dev)
+    e = (torch.randn(B, V, V, C, H) + 4.0).to(dev)
+    xh, eh = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    x1, e1 = layer(xh, eh)
+    keep = float((e1 != 0).float().mean())
+    assert abs(keep - (1 - p)) < 0.03
+    x2, e2 = layer(x, e)
+    assert not torch.equal(e1 != 0, e2 != 0)
+    # p = 0 in train mode equals eval mode
+    layer0 = ResidualGatedGCNLayer(H, "mean", dropout_rate=0.0).to(dev)
+    layer0.train()
+    a = layer0(x, e)
+    layer0.eval()
+    b = layer0(x, e)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
