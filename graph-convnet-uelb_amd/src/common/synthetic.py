@@ -98,4 +98,7 @@ CONFIGS = {
     "default2": dict(V=40, C=5, H=64, L=10, B=20, topology="random", cap_lo=1000, cap_hi=10000, dem_lo=1, dem_hi=500),
     "nsfnet_10_commodities": dict(V=14, C=10, H=64, L=10, B=20, topology="nsfnet", cap_lo=1000, cap_hi=5000, dem_lo=5, dem_hi=500),
     "nsfnet_20_commodities": dict(V=14, C=20, H=64, L=10, B=20, topology="nsfnet", cap_lo=2000, cap_hi=10000, dem_lo=5, dem_hi=500),
+    # the two large synthetic shapes (graphs per GPU chosen to fit one 288 GB device with room to spare)
+    "synthetic_100n_50c_h300_l30": dict(V=100, C=50, H=300, L=30, B=2, topology="random", cap_lo=1000, cap_hi=10000, dem_lo=1, dem_hi=500),
+    "synthetic_200n_100c": dict(V=200, C=100, H=64, L=10, B=4, topology="random", cap_lo=1000, cap_hi=10000, dem_lo=1, dem_hi=500),
 }
