@@ -117,6 +117,8 @@ int check_dims(int B, int V, int C, int H) {
     if (H > GCN_MAX_H) return fail(-1, "hidden_dim %d > %d is not supported by this build", H, GCN_MAX_H);
     if ((double)B * V * V * C * H >= 4.0e9 * 16) return fail(-1, "problem too large");
     if ((double)B * V * V * C >= 4.0e9) return fail(-1, "more than 2^32 edge rows");
+    if ((double)B * V * C * H * 4.0 >= 2147483648.0) return fail(-1, "node tensors of 2 GiB or more are not supported");
+    if (16.0 * C * H * 4.0 >= 2147483648.0) return fail(-1, "a 16-row edge tile of 2 GiB or more is not supported");
     return 0;
 }
 
