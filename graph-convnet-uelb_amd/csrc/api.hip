@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1083,6 +1084,34 @@ int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* pa
     GCN_PROF_PRE("k_max_load_factor");
     k_max_load_factor<<<B, 256, 0, st>>>(V, usage_ws, cap, max_lf);
     GCN_CHECK_LAUNCH("k_max_load_factor");
+    return 0;
+}
+
+int gcn_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, long long step, void* stream) {
+    if (n < 0 || step < 1) return fail(-1, "gcn_adam_step: n %d < 0 or step %lld < 1", n, step);
+    if (n > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)) return fail(-1, "gcn_adam_step: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+    for (int i0 = 0; i0 < n; i0 += ADAM_CHUNK) {
+        AdamChunk c = {};
+        c.n = std::min(ADAM_CHUNK, n - i0);
+        long long maxn = 0;
+        for (int k = 0; k < c.n; ++k) {
+            if (numel[i0 + k] < 0 || (numel[i0 + k] > 0 && (!params[i0 + k] || !grads[i0 + k] || !exp_avg[i0 + k] || !exp_avg_sq[i0 + k])))
+                return fail(-1, "gcn_adam_step: tensor %d has a null pointer or a negative size", i0 + k);
+            c.p[k] = params[i0 + k]; c.g[k] = grads[i0 + k]; c.m[k] = exp_avg[i0 + k]; c.v[k] = exp_avg_sq[i0 + k];
+            c.numel[k] = numel[i0 + k];
+            maxn = std::max(maxn, numel[i0 + k]);
+        }
+        if (maxn == 0) continue;
+        const int bx = (int)std::max<long long>(1, std::min<long long>((maxn + 1023) / 1024, 256));
+        GCN_PROF_PRE("k_adam");
+        k_adam<<<dim3(bx, c.n, 1), 256, 0, st>>>(c, step_size, beta1, beta2, eps, weight_decay, inv_sqrt_bc2);
+        GCN_CHECK_LAUNCH("k_adam");
+    }
     return 0;
 }
 

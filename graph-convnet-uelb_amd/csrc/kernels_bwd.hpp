@@ -471,3 +471,35 @@ __global__ void k_loss_edges_bwd(size_t rows, const float* __restrict__ logits, 
         dlogits[r * 2 + 1] = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Multi-tensor Adam (torch.optim.Adam arithmetic, see gcn_adam_step): blockIdx.y = tensor of the chunk,
+// grid-stride over its elements.
+// ------------------------------------------------------------------------------------------------
+constexpr int ADAM_CHUNK = 64;
+struct AdamChunk {
+    float* p[ADAM_CHUNK];
+    const float* g[ADAM_CHUNK];
+    float* m[ADAM_CHUNK];
+    float* v[ADAM_CHUNK];
+    long long numel[ADAM_CHUNK];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_adam(AdamChunk c, float step_size, float b1, float b2, float eps, float wd,
+                                              float inv_sqrt_bc2) {
+    const int k = blockIdx.y;
+    float* __restrict__ p = c.p[k];
+    const float* __restrict__ g = c.g[k];
+    float* __restrict__ m = c.m[k];
+    float* __restrict__ v = c.v[k];
+    const long long n = c.numel[k];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}

@@ -91,6 +91,10 @@ def _declare(lib):
         lib.gcn_load_factor.restype = c_int
         lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]
+    if hasattr(lib, "gcn_adam_step"):
+        lib.gcn_adam_step.restype = c_int
+        lib.gcn_adam_step.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, c_void_p]
 
 
 def load():

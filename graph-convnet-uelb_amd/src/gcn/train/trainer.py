@@ -21,6 +21,7 @@ import torch
 
 from ...common.data_management.dataset_reader import DatasetReader
 from ..hip import dist as D
+from ..hip.fused_adam import FusedAdam
 from ..hip.train_step import HipTrainStep
 from ..models.gcn_model import ResidualGatedGCNModel
 from ..models.model_utils import update_learning_rate
@@ -36,7 +37,8 @@ class Trainer:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.net = ResidualGatedGCNModel(config, dtypeFloat, dtypeLong).to(self.device)
         D.broadcast_parameters(self.net.parameters())
-        self.optimizer = torch.optim.Adam(self.net.parameters(), lr=config.learning_rate)
+        # the reference builds torch.optim.Adam(lr) here (trainer.py:95); same arithmetic and state layout, one launch per step
+        self.optimizer = FusedAdam(self.net.parameters(), lr=config.learning_rate)
         strategy_type = config.get('training_strategy', 'supervised')
         if strategy_type != 'supervised':
             raise ValueError(f"training strategy {strategy_type!r} is not available in this build (supervised only)")

@@ -167,6 +167,19 @@ int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, 
 int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
                     const long long* comm, int* usage_ws, float* max_lf, unsigned char* complete, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Adam update of n parameter tensors in one or a few launches (multi-tensor).  Replaces the
+ * torch.optim.Adam(lr) step of the trainer (src/gcn/train/trainer.py:95,
+ * src/gcn/training/supervised_strategy.py:98-100) with the same arithmetic (no amsgrad; weight_decay is the
+ * L2 form added to the gradient; bias corrections from `step`, the 1-based count of this update):
+ *   g += wd * p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * params / grads / exp_avg / exp_avg_sq: host arrays of n device pointers (fp32), numel: host array of n sizes.
+ * ---------------------------------------------------------------------------------------------- */
+int gcn_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, long long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
