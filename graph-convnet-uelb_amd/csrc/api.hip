@@ -1018,10 +1018,14 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
 }
 
 // ---- beam search ---------------------------------------------------------------------------------
+// workspace: working capacities [B][V][V] (strict mode when they do not fit LDS), then the speculative
+// per-commodity results: lengths [B][C] and paths [B][C][max(V, 10)]
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
-    (void)C; (void)K;
-    if (B <= 0 || V <= 0) return 0;
-    return align_up((size_t)B * V * V * sizeof(float));
+    (void)K;
+    if (B <= 0 || V <= 0 || C <= 0) return 0;
+    const int PL = V > 10 ? V : 10;
+    return align_up((size_t)B * V * V * sizeof(float)) + align_up((size_t)B * C * sizeof(int)) +
+           align_up((size_t)B * C * PL * sizeof(int));
 }
 
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
@@ -1048,10 +1052,27 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
     }
     const int jobs = algorithm == BEAM_ALGO_UNCONSTRAINED ? B * C : B;
     hipStream_t st = (hipStream_t)stream;
+    // speculative pass over all (graph, commodity) pairs, when the workspace has room for its results
+    int *spec_len = nullptr, *spec_paths = nullptr;
+    if (algorithm != BEAM_ALGO_UNCONSTRAINED && ws && ws_bytes >= gcn_beam_ws_bytes(B, V, C, K)) {
+        char* base = (char*)ws + align_up((size_t)B * V * V * sizeof(float));
+        spec_len = (int*)base;
+        spec_paths = (int*)(base + align_up((size_t)B * C * sizeof(int)));
+        int spec_cap_lds = (size_t)V * V * sizeof(float) <= 32768 ? 1 : 0;
+        if (beam_lds_bytes(V, K, spec_cap_lds) > 160 * 1024) spec_cap_lds = 0;
+        const size_t slds = beam_lds_bytes(V, K, spec_cap_lds);
+        if (slds > 48 * 1024) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+                return fail(-3, "gcn_beam_search: cannot raise the dynamic LDS limit to %zu bytes", slds);
+        }
+        GCN_PROF_PRE("k_beam_spec");
+        k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths, spec_len);
+        GCN_CHECK_LAUNCH("k_beam_spec");
+    }
     GCN_PROF_PRE("k_beam_search");
     k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, strict ? 1 : 0, max_iter, y, cap, comm, perms,
                                                           n_perms, perm_start, run_mask, (float*)ws, cap_in_lds, paths, path_len,
-                                                          feasible, attempts);
+                                                          feasible, attempts, spec_paths, spec_len);
     GCN_CHECK_LAUNCH("k_beam_search");
     return 0;
 }
@@ -1064,7 +1085,6 @@ int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, 
         k_beam_scores_2class<<<elem_blocks(rows), 256, 0, st>>>(rows, in, y);
     } else {
         k_beam_scores_over_j<<<elem_blocks((size_t)B * V * C), 256, 0, st>>>(B, V, C, in, y);
-    GCN_PROF_PRE("k_beam_scores");
     }
     GCN_CHECK_LAUNCH("k_beam_scores");
     return 0;

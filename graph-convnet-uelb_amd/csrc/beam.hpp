@@ -23,6 +23,7 @@
 #define BEAM_ALGO_DETERMINISTIC 1
 #define BEAM_ALGO_GREEDY 2
 #define BEAM_ALGO_UNCONSTRAINED 3
+#define BEAM_CPL 4              // candidates per lane kept in registers when K * V <= 64 * BEAM_CPL
 
 struct BeamCand {
     float score;
@@ -46,6 +47,33 @@ __device__ __forceinline__ BeamCand beam_wave_best(BeamCand c) {
         if (beam_better(o, c)) c = o;
     }
     return c;
+}
+
+// The same arg-max without LDS permutes: rotations inside each row of 16 lanes (DPP), then the four row
+// winners are read as scalars.  Every lane returns the wavefront's best candidate.
+template <int ROT>
+__device__ __forceinline__ BeamCand beam_dpp_ror(const BeamCand& c) {
+    BeamCand o;
+    o.score = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c.score), 0x120 + ROT, 0xf, 0xf, false));
+    o.idx = __builtin_amdgcn_update_dpp(0, c.idx, 0x120 + ROT, 0xf, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ BeamCand beam_wave_best_dpp(BeamCand c) {
+    BeamCand o;
+    o = beam_dpp_ror<8>(c); if (beam_better(o, c)) c = o;
+    o = beam_dpp_ror<4>(c); if (beam_better(o, c)) c = o;
+    o = beam_dpp_ror<2>(c); if (beam_better(o, c)) c = o;
+    o = beam_dpp_ror<1>(c); if (beam_better(o, c)) c = o;
+    BeamCand best;
+    best.score = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.score), 0));
+    best.idx = __builtin_amdgcn_readlane(c.idx, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        o.score = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.score), 16 * row));
+        o.idx = __builtin_amdgcn_readlane(c.idx, 16 * row);
+        if (beam_better(o, best)) best = o;
+    }
+    return best;
 }
 
 // LDS carve (bytes), all regions 16-byte aligned:
@@ -127,53 +155,106 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
         }
         // expansion: candidate (k, n) in beam-rank order, n ascending
         const int ncand = nb * V;
-        int any = 0;
-        for (int idx = lane; idx < ncand; idx += 64) {
-            const int k = idx / V, n = idx - k * V;
-            const int node = gnode[k];
-            bool ok = node != dst;
-            ok = ok && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
-            float sc = 0.f;
-            if (ok) {
-                const float cv = capm[node * V + n];
-                ok = (cv != 0.f) && (!check_demand || demand <= cv);
-                if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
-            }
-            L.cand_score[idx] = sc;
-            L.cand_ok[idx] = ok ? 1 : 0;
-            any |= ok ? 1 : 0;
-        }
-        __syncthreads();
-        if (!__any(any)) break;
-        // stable top-K: K rounds of arg-max over (score desc, idx asc)
         const int ngen = gen ^ 1;
         unsigned short* npath = L.path + (size_t)ngen * K * V;
         unsigned int* nvis = L.visited + (size_t)ngen * K * VW;
         int nnb = 0;
-        for (int r = 0; r < K; ++r) {
-            BeamCand c;
-            c.idx = -1; c.score = 0.f;
-            for (int idx = lane; idx < ncand; idx += 64) {
-                if (L.cand_ok[idx]) {
-                    BeamCand o;
-                    o.idx = idx; o.score = L.cand_score[idx];
-                    if (beam_better(o, c)) c = o;
+        if (K * V <= 64 * BEAM_CPL) {
+            // candidates stay in registers (lane owns idx = lane + 64 j); no LDS traffic and no barrier per round
+            float cs[BEAM_CPL];
+            bool ck[BEAM_CPL];
+            int any = 0;
+#pragma unroll
+            for (int j = 0; j < BEAM_CPL; ++j) {
+                const int idx = lane + 64 * j;
+                bool ok = idx < ncand;
+                float sc = 0.f;
+                if (ok) {
+                    const int k = idx / V, n = idx - k * V;
+                    const int node = gnode[k];
+                    ok = node != dst && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
+                    if (ok) {
+                        const float cv = capm[node * V + n];
+                        ok = (cv != 0.f) && (!check_demand || demand <= cv);
+                        if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
+                    }
                 }
+                cs[j] = sc; ck[j] = ok;
+                any |= ok ? 1 : 0;
             }
-            c = beam_wave_best(c);
-            if (c.idx < 0) break;
-            const int k = c.idx / V, n = c.idx - k * V;
-            if (lane == 0) {
-                L.cand_ok[c.idx] = 0;
-                L.beam_node[ngen * K + r] = n;
-                L.beam_score[ngen * K + r] = c.score;
-                npath[(size_t)r * V + len] = (unsigned short)n;
+            if (!__any(any)) break;
+            for (int r = 0; r < K; ++r) {
+                BeamCand c;
+                c.idx = -1; c.score = 0.f;
+#pragma unroll
+                for (int j = 0; j < BEAM_CPL; ++j) {
+                    if (ck[j]) {
+                        BeamCand o;
+                        o.idx = lane + 64 * j; o.score = cs[j];
+                        if (beam_better(o, c)) c = o;
+                    }
+                }
+                c = beam_wave_best_dpp(c);
+                if (c.idx < 0) break;
+#pragma unroll
+                for (int j = 0; j < BEAM_CPL; ++j)
+                    if (lane + 64 * j == c.idx) ck[j] = false;
+                const int k = c.idx / V, n = c.idx - k * V;
+                if (lane == 0) {
+                    L.beam_node[ngen * K + r] = n;
+                    L.beam_score[ngen * K + r] = c.score;
+                    npath[(size_t)r * V + len] = (unsigned short)n;
+                }
+                for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
+                for (int w = lane; w < VW; w += 64)
+                    nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+                nnb = r + 1;
             }
-            for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
-            for (int w = lane; w < VW; w += 64)
-                nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
-            nnb = r + 1;
+        } else {
+            int any = 0;
+            for (int idx = lane; idx < ncand; idx += 64) {
+                const int k = idx / V, n = idx - k * V;
+                const int node = gnode[k];
+                bool ok = node != dst;
+                ok = ok && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
+                float sc = 0.f;
+                if (ok) {
+                    const float cv = capm[node * V + n];
+                    ok = (cv != 0.f) && (!check_demand || demand <= cv);
+                    if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
+                }
+                L.cand_score[idx] = sc;
+                L.cand_ok[idx] = ok ? 1 : 0;
+                any |= ok ? 1 : 0;
+            }
             __syncthreads();
+            if (!__any(any)) break;
+            // stable top-K: K rounds of arg-max over (score desc, idx asc)
+            for (int r = 0; r < K; ++r) {
+                BeamCand c;
+                c.idx = -1; c.score = 0.f;
+                for (int idx = lane; idx < ncand; idx += 64) {
+                    if (L.cand_ok[idx]) {
+                        BeamCand o;
+                        o.idx = idx; o.score = L.cand_score[idx];
+                        if (beam_better(o, c)) c = o;
+                    }
+                }
+                c = beam_wave_best(c);
+                if (c.idx < 0) break;
+                const int k = c.idx / V, n = c.idx - k * V;
+                if (lane == 0) {
+                    L.cand_ok[c.idx] = 0;
+                    L.beam_node[ngen * K + r] = n;
+                    L.beam_score[ngen * K + r] = c.score;
+                    npath[(size_t)r * V + len] = (unsigned short)n;
+                }
+                for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
+                for (int w = lane; w < VW; w += 64)
+                    nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+                nnb = r + 1;
+                __syncthreads();
+            }
         }
         gen = ngen; nb = nnb; len += 1;
         __syncthreads();
@@ -192,7 +273,7 @@ __global__ __launch_bounds__(64) void k_beam_search(
     const float* __restrict__ cap, const long long* __restrict__ comm, const int* __restrict__ perms, int n_perms,
     const int* __restrict__ perm_start, const unsigned char* __restrict__ run_mask, float* __restrict__ capws,
     int cap_in_lds, int* __restrict__ paths, int* __restrict__ path_len, int* __restrict__ feasible,
-    int* __restrict__ attempts) {
+    int* __restrict__ attempts, const int* __restrict__ spec_paths, const int* __restrict__ spec_len) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
@@ -238,7 +319,26 @@ __global__ __launch_bounds__(64) void k_beam_search(
             const int c = perm ? perm[pos] : pos;
             const int s = (int)cm[c * 3], d = (int)cm[c * 3 + 1];
             const float demand = (float)cm[c * 3 + 2];
-            const int len = beam_commodity(L, strict ? wcap : cap_b, yb + c, V, C, K, s, d, demand, 1);
+            // A commodity's search depends on the capacities only through the edge predicate
+            // (cap != 0 and demand <= cap).  If that predicate is the same on the working capacities as on the
+            // initial ones, the search k_beam_spec ran against the initial capacities is this search exactly.
+            bool reuse = spec_len != nullptr;
+            if (reuse && strict) {
+                int diff = 0;
+                for (int t = lane; t < V * V; t += 64) {
+                    const float c0 = cap_b[t], c1 = wcap[t];
+                    diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
+                }
+                reuse = !__any(diff);
+            }
+            int len;
+            if (reuse) {
+                len = spec_len[(size_t)b * C + c];
+                for (int t = lane; t < len; t += 64) L.best_path[t] = (unsigned short)spec_paths[((size_t)b * C + c) * PL + t];
+                __syncthreads();
+            } else {
+                len = beam_commodity(L, strict ? wcap : cap_b, yb + c, V, C, K, s, d, demand, 1);
+            }
             if (len == 0) { ok = 0; break; }
             for (int t = lane; t < PL; t += 64) pb[(size_t)c * PL + t] = t < len ? (int)L.best_path[t] : -1;
             if (lane == 0) plb[c] = len;
@@ -265,6 +365,32 @@ __global__ __launch_bounds__(64) void k_beam_search(
 
 // y from the network output, BeamSearchAlgorithm.__init__ (:14-21).
 // five_d != 0: logits [rows][2] -> y[row] = log_softmax(.)[1]; thread per row.
+// Every (graph, commodity) searched against the graph's initial capacities, all in parallel: one wavefront
+// per job.  k_beam_search then walks the commodities in order and keeps a result whenever the capacity
+// updates so far leave the commodity's edge predicate unchanged (the common case), re-searching otherwise.
+__global__ __launch_bounds__(64) void k_beam_spec(
+    int B, int V, int C, int K, int algo, const float* __restrict__ y, const float* __restrict__ cap,
+    const long long* __restrict__ comm, const unsigned char* __restrict__ run_mask, int cap_in_lds,
+    int* __restrict__ spec_paths, int* __restrict__ spec_len) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int PL = V > 10 ? V : 10;
+    const BeamLds L = beam_carve(smem, V, K, cap_in_lds);
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    if (run_mask && !run_mask[b]) return;
+    if (algo == BEAM_ALGO_GREEDY) K = 1;
+    const float* cap_b = cap + (size_t)b * V * V;
+    if (L.wcap) {
+        for (int t = lane; t < V * V; t += 64) L.wcap[t] = cap_b[t];
+        __syncthreads();
+    }
+    const long long* cm = comm + ((size_t)b * C + c) * 3;
+    const int len = beam_commodity(L, L.wcap ? L.wcap : cap_b, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
+                                   (float)cm[2], 1);
+    for (int t = lane; t < len; t += 64) spec_paths[((size_t)b * C + c) * PL + t] = (int)L.best_path[t];
+    if (lane == 0) spec_len[(size_t)b * C + c] = len;
+}
+
 __global__ void k_beam_scores_2class(size_t rows, const float* __restrict__ logits, float* __restrict__ y) {
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
         const float l0 = logits[r * 2], l1 = logits[r * 2 + 1];

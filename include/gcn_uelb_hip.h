@@ -143,7 +143,11 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
  * run_mask uint8 [B] (NULL = all): graphs with 0 are skipped and their outputs left untouched.
  * Outputs: paths int32 [B,C,PL] padded with -1, PL = max(V, 10); path_len int32 [B,C];
  * feasible int32 [B]; attempts int32 [B] (permutations consumed by standard / greedy).
- * ws: gcn_beam_ws_bytes() bytes, used only in strict mode when V*V*4 > 32 KiB.
+ * ws: gcn_beam_ws_bytes() bytes: working capacities for strict mode when V*V*4 > 32 KiB, and the results of a
+ *     first pass that searches every (graph, commodity) against the initial capacities in parallel; the ordered
+ *     pass keeps such a result whenever the capacity updates so far leave that commodity's edge predicate
+ *     (cap != 0 and demand <= cap) unchanged, and searches again otherwise: same paths as the sequential
+ *     reference order, bit for bit.  With a smaller or null ws the first pass is skipped.
  * ---------------------------------------------------------------------------------------------- */
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K);
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,

@@ -123,3 +123,34 @@ def test_beam_matches_c_oracle_at_benchmark_sizes(algo, strict, V, C, K, B):
     assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
     if algo in ("standard", "greedy"):
         assert int(a.attempts.sum()) == used
+
+
+@pytest.mark.parametrize("algo,V,C,K,B,seed", [("deterministic", 14, 10, 10, 30, 1), ("standard", 14, 20, 10, 30, 2),
+                                               ("greedy", 14, 10, 10, 30, 3), ("deterministic", 40, 12, 5, 10, 4),
+                                               ("standard", 100, 6, 4, 4, 5)])
+def test_beam_tight_capacities_match_c_oracle(algo, V, C, K, B, seed):
+    """Strict mode with capacities of the order of the demands: earlier commodities' paths change which edges later
+    ones may use, attempts fail and are retried.  This exercises both branches of the ordered pass (keeping the result
+    of the parallel first pass, and searching again on the updated capacities) against the sequential C oracle."""
+    from src.common.synthetic import make_batch
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    b = make_batch(B, V, C, "nsfnet" if V == 14 else "random", 100, 700, 5, 500, seed=seed)
+    y = np.log(rng.random((B, V, V, C)).astype(np.float32) * 0.98 + 0.01).astype(np.float32)
+    y[rng.random(y.shape) < 0.2] = np.float32(-0.5)
+    max_iter = 5
+    perms = np.stack([rng.permutation(C) for _ in range(B * max_iter)]).astype(np.int32)
+    rp, rl, rf, ratt, used = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, algo, True, max_iter, perms)
+    a = _make(algo, y, b["edges_capacity"], b["commodities"], K, True, max_iter, dev)
+    it = iter([torch.from_numpy(p.astype(np.int64)) for p in perms])
+    orig = torch.randperm
+    torch.randperm = lambda n, *args, **kw: next(it, torch.arange(n))
+    try:
+        a.search()
+    finally:
+        torch.randperm = orig
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+    if algo in ("standard", "greedy"):
+        assert int(a.attempts.sum()) == used
