@@ -491,6 +491,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
 // ---- model-level plans -----------------------------------------------------------------------------
 struct ModelPlan {
     Dims d;
+    bool whead;
     int L, NHID, voc, nparams, n_emb;
     size_t x_act, e_act, lsaved;    // float offsets inside `saved`
     size_t lsaved_each, total_saved;
@@ -499,6 +500,9 @@ ModelPlan make_plan(const gcn_model_desc* m) {
     ModelPlan p;
     p.d = make_dims(m->B, m->V, m->C, m->H);
     p.L = m->L; p.NHID = m->mlp_layers - 1; p.voc = m->voc_out; p.n_emb = m->n_emb;
+    // the workgroup-per-tile head kernels (one partial row per workgroup): k_head_*_w above H = 64, k_head_*3 up to
+    // one hidden layer below it; deeper heads at H <= 64 use the wavefront-per-tile kernels
+    p.whead = p.d.MT > 4 || (p.NHID <= 1 && getenv("GCN_TUNE_OLDHEAD") == nullptr);
     p.nparams = 3 + GCN_LAYER_NPARAMS * m->L + 2 * m->mlp_layers;
     const size_t nh = p.d.Rn * p.d.H, eh = p.d.Re * p.d.H;
     p.lsaved_each = layer_saved_floats(p.d);
@@ -573,12 +577,18 @@ template <int MT, int NHID>
 void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const float* cap,
                      const long long* y_edges, const float* edge_cw, float* y_pred, float* loss_partial, int* counts,
                      const unsigned long long* rng, int blocks, hipStream_t st) {
-    if constexpr (MT == 0) {
-        if constexpr (NHID <= 1)
-            k_head_fwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
-                                                       m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
-                                                       m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
-    } else
+    if (p.whead) {
+        if constexpr (NHID <= 1) {
+            if constexpr (MT == 0)
+                k_head_fwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
+                                                           m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                           m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
+            else
+                k_head_fwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
+                                                                  m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                                  m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
+        }
+    } else if constexpr (MT != 0)
     k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
                                                         m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
                                                         m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp,
@@ -589,12 +599,19 @@ void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadPara
                      float* e_stash, const float* cap, const long long* y_edges, const float* edge_cw, const float* loss_out,
                      const float* dloss, const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
                      const unsigned long long* rng, int blocks, const ZeroJobs& z, const float* hidWt, hipStream_t st) {
-    if constexpr (MT == 0) {
-        if constexpr (NHID <= 1)
-            k_head_bwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, hidWt, src, next, e_stash, cap,
-                                                       m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
-                                                       dloss, dy_pred, de, dpre, wpartial, rng, 1000, m->p_mlp, m->training, z);
-    } else
+    if (p.whead) {
+        if constexpr (NHID <= 1) {
+            if constexpr (MT == 0)
+                k_head_bwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, hidWt, src, next, e_stash, cap,
+                                                           m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
+                                                           dloss, dy_pred, de, dpre, wpartial, rng, 1000, m->p_mlp, m->training, z);
+            else
+                k_head_bwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, hidWt, src, next, e_stash, cap,
+                                                                  m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw,
+                                                                  loss_out, dloss, dy_pred, de, dpre, wpartial, rng, 1000, m->p_mlp,
+                                                                  m->training, z);
+        }
+    } else if constexpr (MT != 0)
     k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, next, e_stash, cap,
                                                         m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw, loss_out,
                                                         dloss, dy_pred, de, dpre, hst, wpartial, rng, 1000, m->p_mlp, m->training, z);
@@ -786,7 +803,7 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     GCN_CHECK_LAUNCH("k_head_fwd");
     if (m->has_labels) {
         GCN_PROF_PRE("k_loss_finalize");
-        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, d.MT > 4 ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
+        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
                                                  err_flags);
         GCN_CHECK_LAUNCH("k_loss_finalize");
     }
@@ -820,7 +837,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         const int idx[4] = {0, 2, 4, 6};
         for (int l = 0; l < p.L; ++l)
             for (int k = 0; k < 4; ++k) tr.emplace_back(P[3 + GCN_LAYER_NPARAMS * l + idx[k]], W.wT + (size_t)(4 * l + k) * hh2);
-        if (d.MT > 4 && p.NHID == 1) tr.emplace_back(hp.hidW[0], W.wT + (size_t)4 * p.L * hh2);   // the wide head reads W_0^T
+        if (p.whead && p.NHID == 1) tr.emplace_back(hp.hidW[0], W.wT + (size_t)4 * p.L * hh2);   // the tile-per-workgroup head reads W_0^T
         for (size_t i0 = 0; i0 < tr.size(); i0 += 64) {
             TransposeList tl = {};
             const int n = (int)std::min<size_t>(64, tr.size() - i0);
@@ -864,7 +881,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
         // output-layer gradients, hidden-layer weight gradients and the BatchNorm backward of the top layer
         ReduceJobs jobs = {};
-        jobs.job[0].partial = W.wpartial; jobs.job[0].nP = d.MT > 4 ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
+        jobs.job[0].partial = W.wpartial; jobs.job[0].nP = p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
         jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[hbase + 2 * p.NHID]; jobs.job[0].rd.dst[1] = G[hbase + 2 * p.NHID + 1];
         jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = p.voc * H; jobs.job[0].rd.off[2] = p.voc * H + p.voc;
         int maxcols = std::max(wcols, 2 * H);
@@ -967,7 +984,9 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         k_embed_bwd_rowsum<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt);
         GCN_CHECK_LAUNCH("k_embed_bwd_rowsum");
         GCN_PROF_PRE("k_embed_bwd_nodes");
-        k_embed_bwd_nodes<<<m->n_emb + 1, GCN_BLOCK, GCN_BLOCK * sizeof(double), st>>>(d.B * d.V, d.C, H, m->n_emb, W.emb_g,
+        // many short chains of dependent loads: wide workgroups (hh * parts threads) keep the chains short
+        const int eb_threads = std::max(GCN_BLOCK, std::min(1024, (1024 / std::max(H / 2, 1)) * (H / 2)));
+        k_embed_bwd_nodes<<<m->n_emb + 1, eb_threads, eb_threads * sizeof(double), st>>>(d.B * d.V, d.C, H, m->n_emb, W.emb_g,
                                                                                     W.emb_cnt, G[0], G[1]);
         GCN_CHECK_LAUNCH("k_embed_bwd_nodes");
     }

@@ -384,7 +384,7 @@ __global__ void k_embed_bwd_rowsum(int V, int C, int H, int n_emb, const long lo
 }
 
 // one workgroup per embedding row v (blockIdx.x < n_emb) plus one (blockIdx.x == n_emb) for d w_c
-__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
                                                               const int* __restrict__ cnt, float* __restrict__ demb,
                                                               float* __restrict__ dwc) {
     extern __shared__ double lds_d[];     // [blockDim.x]

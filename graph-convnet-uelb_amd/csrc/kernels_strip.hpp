@@ -700,3 +700,264 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_wgrad(int H, TnProblems pr, Reduc
     if (k < 4) gemm_tn_body<MT>(H, pr, k, idx, L);
     else reduce_slab_body(jobs.job[k - 4], idx, lds);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Head (edge MLP with at most one hidden layer, masking, loss, edge error) in the strip layout, H <= 64.
+// Forward: same outputs as k_head_fwd; loss_partial has one row per workgroup.
+// Phase A builds the head's input tile from EdgeSrc; phase B: wavefront w computes hidden columns 16 w ..,
+// their share of the two output dot products, and the workgroup adds the four shares through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int MT>
+__device__ __forceinline__ f32x4 head_src4(const EdgeSrc& S, const float (*cl)[16 * MT], const DropCfg& dc, size_t row, bool valid,
+                                           int H, int C, int acol, int ag) {
+    f32x4 val = f4zero();
+    if (!valid) return val;
+    const size_t off = row * H + acol;
+    if (S.mode == 0) return ld4(S.e_in + off);
+    if (S.mode == 2) return ld4(&cl[CL_WE][acol]) * S.cap[row / C];
+    const f32x4 tp = ld4(S.prev_tmp + off), rin = ld4(S.prev_in + off);
+    const f32x4 pm = ld4(&cl[CL_PMEAN][acol]), pr = ld4(&cl[CL_PRSTD][acol]);
+    const f32x4 pg = ld4(&cl[CL_PGAMMA][acol]), pb = ld4(&cl[CL_PBETA][acol]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float bn = (tp[k] - pm[k]) * pr[k] * pg[k] + pb[k];
+        val[k] = (bn > 0.f ? bn : 0.f) + rin[k];
+    }
+    if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), ag);
+    return val;
+}
+
+template <int MT, int NHID>
+__global__ __launch_bounds__(64 * MT) void k_head_fwd3(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, const float* __restrict__ cap, int mask_invalid,
+    const long long* __restrict__ y_edges, const float* __restrict__ edge_cw, float* __restrict__ logits,
+    float* __restrict__ loss_partial, int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0,
+    float p, int training) {
+    static_assert(NHID <= 1, "at most one hidden layer");
+    using GM = StripGeom<MT>;
+    __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GM::HP];
+    __shared__ float red[2][MT][16][2];
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    edge_src_fill_consts<MT>(cl, src, H);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
+    f32x4 wf[MT];
+    if (NHID) strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q);
+    const f32x4 b1 = (NHID && bcol_ok) ? ld4(hp.hidB[0] + bcol) : f4zero();
+    const f32x4 w0 = bcol_ok ? ld4(hp.outW + bcol) : f4zero();
+    const f32x4 w1 = (bcol_ok && voc > 1) ? ld4(hp.outW + H + bcol) : f4zero();
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    const size_t ntiles = (rows + 15) / 16;
+    const int BC_stride = V * V * C;
+    float acc_wn = 0.f, acc_w = 0.f;
+    int buf = 0;
+    __syncthreads();
+    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        {
+            const size_t row = tl * 16 + arow;
+            st4(&tile[buf][arow][acol], head_src4<MT>(src, cl, sdc, row, row < rows && acol_ok, H, C, acol, ag));
+        }
+        __syncthreads();
+        const size_t row = tl * 16 + rs;
+        f32x4 h;
+        if (NHID) {
+            h = strip_gemm<MT>(tile[buf], wf, rs, q) + b1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = h[r] > 0.f ? h[r] : 0.f;
+            if (hdc.on) h *= drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)row), bcol >> 2);
+        } else {
+            h = ld4(&tile[buf][rs][bcol]);
+        }
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p0 += h[r] * w0[r]; p1 += h[r] * w1[r]; }
+        p0 = redq(p0); p1 = redq(p1);
+        if (q == 0) { red[buf][w][rs][0] = p0; red[buf][w][rs][1] = p1; }
+        __syncthreads();
+        if (w == 0 && q == 0 && row < rows) {
+            float l0 = b2_0, l1 = b2_1;
+#pragma unroll
+            for (int k = 0; k < MT; ++k) { l0 += red[buf][k][rs][0]; l1 += red[buf][k][rs][1]; }
+            if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+            if (voc == 1) {
+                logits[row] = l0;
+            } else {
+                logits[row * 2] = l0;
+                logits[row * 2 + 1] = l1;
+                if (y_edges != nullptr) {
+                    const int y = (int)y_edges[row];
+                    const float mx = fmaxf(l0, l1);
+                    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+                    const float wgt = y ? cw1 : cw0;
+                    acc_wn += -wgt * ((y ? l1 : l0) - lse);
+                    acc_w += wgt;
+                    const int pred = l1 > l0 ? 1 : 0;
+                    if (y + pred > 0) {
+                        const int b = (int)(row / BC_stride), c = (int)(row % C);
+                        const int BC = (int)(rows / BC_stride) * C;
+                        atomicAdd(&counts[BC + b * C + c], 1);
+                        if (pred == y) atomicAdd(&counts[b * C + c], 1);
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    if (loss_partial != nullptr && w == 0) {
+        acc_wn = red16(acc_wn);      // lanes with q != 0 hold zeros
+        acc_w = red16(acc_w);
+        if (t == 0) {
+            loss_partial[(size_t)blockIdx.x * 2] = acc_wn;
+            loss_partial[(size_t)blockIdx.x * 2 + 1] = acc_w;
+        }
+    }
+}
+
+// Backward (same outputs as k_head_bwd, NHID <= 1); wpartial has one row per workgroup, hidWt is the transposed
+// hidden weight.
+template <int MT, int NHID>
+__global__ __launch_bounds__(64 * MT) void k_head_bwd3(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ hidWt, EdgeSrc src, NextBn next,
+    float* __restrict__ e_stash, const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
+    const float* __restrict__ edge_cw, const float* __restrict__ loss_out, const float* __restrict__ dloss,
+    const float* __restrict__ dy_pred, float* __restrict__ de, float* __restrict__ dpre_stash,
+    float* __restrict__ wpartial, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z) {
+    static_assert(NHID <= 1, "at most one hidden layer");
+    using GM = StripGeom<MT>;
+    __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float tdp[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GM::HP];
+    __shared__ float red[2][MT][16][2];
+    zero_fill(z);
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
+    const bool acol_ok = acol < H;
+    const int bcol = 16 * w + 4 * q;
+    const bool bcol_ok = bcol < H;
+    edge_src_fill_consts<MT>(cl, src, H);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
+    const bool do_next = next.tmp != nullptr;
+    f32x4 wf[MT], wft[MT];
+    if (NHID) { strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q); strip_wfrag<MT>(wft, hidWt, H, w, rs, q); }
+    const f32x4 b1 = (NHID && bcol_ok) ? ld4(hp.hidB[0] + bcol) : f4zero();
+    const f32x4 w0 = bcol_ok ? ld4(hp.outW + bcol) : f4zero();
+    const f32x4 w1 = (bcol_ok && voc > 1) ? ld4(hp.outW + H + bcol) : f4zero();
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    const bool has_loss = (y_edges != nullptr) && voc == 2;
+    const float gl = has_loss ? (dloss ? dloss[0] : 1.f) / loss_out[1] : 0.f;
+    f32x4 gw0 = f4zero(), gw1 = f4zero(), na1 = f4zero(), na2 = f4zero();
+    float gb0 = 0.f, gb1 = 0.f;
+    const size_t ntiles = (rows + 15) / 16;
+    int buf = 0;
+    __syncthreads();
+    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        {
+            const size_t row = tl * 16 + arow;
+            const bool valid = row < rows && acol_ok;
+            const f32x4 val = head_src4<MT>(src, cl, sdc, row, valid, H, C, acol, ag);
+            if (valid && e_stash != nullptr) st4(e_stash + row * H + acol, val);
+            st4(&tile[buf][arow][acol], val);
+        }
+        __syncthreads();
+        const size_t row = tl * 16 + rs;
+        const bool rvalid = row < rows;
+        f32x4 h, dmul;
+        if (NHID) {
+            const f32x4 pre = strip_gemm<MT>(tile[buf], wf, rs, q) + b1;
+            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (hdc.on) dm = drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dmul[r] = pre[r] > 0.f ? dm[r] : 0.f;
+                h[r] = (pre[r] > 0.f ? pre[r] : 0.f) * dm[r];
+            }
+        } else {
+            h = ld4(&tile[buf][rs][bcol]);
+            dmul = f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p0 += h[r] * w0[r]; p1 += h[r] * w1[r]; }
+        p0 = redq(p0); p1 = redq(p1);
+        if (q == 0) { red[buf][w][rs][0] = p0; red[buf][w][rs][1] = p1; }
+        __syncthreads();
+        float d0 = 0.f, d1 = 0.f;
+        if (rvalid) {
+            const bool masked = mask_invalid && cap[row / C] == 0.f;
+            if (!masked) {
+                if (has_loss) {
+                    float l0 = b2_0, l1 = b2_1;
+#pragma unroll
+                    for (int k = 0; k < MT; ++k) { l0 += red[buf][k][rs][0]; l1 += red[buf][k][rs][1]; }
+                    const int y = (int)y_edges[row];
+                    const float mx = fmaxf(l0, l1);
+                    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
+                    const float wgt = (y ? cw1 : cw0) * gl;
+                    d0 = wgt * (e0 * inv - (y == 0 ? 1.f : 0.f));
+                    d1 = wgt * (e1 * inv - (y == 1 ? 1.f : 0.f));
+                }
+                if (dy_pred != nullptr) {
+                    if (voc == 1) d0 += dy_pred[row];
+                    else { d0 += dy_pred[row * 2]; d1 += dy_pred[row * 2 + 1]; }
+                }
+            }
+        }
+        if (w == 0 && q == 0) { gb0 += d0; gb1 += d1; }
+        f32x4 dp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gw0[r] += d0 * h[r];
+            gw1[r] += d1 * h[r];
+            dp[r] = (d0 * w0[r] + d1 * w1[r]) * dmul[r];
+        }
+        if (NHID && rvalid && bcol_ok) st4(dpre_stash + row * H + bcol, dp);
+        f32x4 dv = dp;
+        if (NHID) {
+            st4(&tdp[buf][rs][bcol], dp);
+            __syncthreads();
+            dv = strip_gemm<MT>(tdp[buf], wft, rs, q);
+        }
+        if (rvalid && bcol_ok) {
+            st4(de + row * H + bcol, dv);
+            if (do_next) {
+                const f32x4 ntp = ld4(next.tmp + row * H + bcol);
+                const f32x4 nmu = ld4(&cl[CL_PMEAN][bcol]), nrs = ld4(&cl[CL_PRSTD][bcol]);
+                const f32x4 nga = ld4(&cl[CL_PGAMMA][bcol]), nbe = ld4(&cl[CL_PBETA][bcol]);
+                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (sdc.on) dm = drop_mul4(sdc, drop_rowhash(sdc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (ntp[r] - nmu[r]) * nrs[r];
+                    const float bn = xh * nga[r] + nbe[r];
+                    const float d = bn > 0.f ? dv[r] * dm[r] : 0.f;
+                    na1[r] += d;
+                    na2[r] += d * xh;
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    const int wstride = (voc * H + voc + 3) & ~3;
+    float* wp = wpartial + (size_t)blockIdx.x * wstride;
+    gw0 = red16x4(gw0); gw1 = red16x4(gw1); na1 = red16x4(na1); na2 = red16x4(na2);
+    if (rs == 0 && bcol_ok) {
+        st4(wp + bcol, gw0);
+        if (voc > 1) st4(wp + H + bcol, gw1);
+        if (do_next) {
+            st4(next.partial + (size_t)blockIdx.x * 2 * H + bcol, na1);
+            st4(next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, na2);
+        }
+    }
+    if (w == 0) {
+        gb0 = red16(gb0); gb1 = red16(gb1);      // lanes with q != 0 hold zeros
+        if (t == 0) { wp[voc * H] = gb0; if (voc > 1) wp[voc * H + 1] = gb1; }
+    }
+}
