@@ -864,46 +864,56 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                                                                       W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2, st))));
     GCN_CHECK_LAUNCH("k_head_bwd");
     int npart_e = W.head_blk, npart_x = 1;
+    // hidden-layer weight-gradient products of the head and the reduce jobs that are ready now: output-layer
+    // gradients and the BatchNorm backward of the top layer.  The slabs of the head's products are reduced by the
+    // top layer's k_wgrad launch (H <= 64) or right here (wider).
+    TnProblems hpr = {};
+    for (int k = 0; k < p.NHID; ++k) {
+        hpr.X[k] = dpre_all + (size_t)k * eh;
+        hpr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
+        hpr.rows[k] = d.Re; hpr.nslices[k] = W.S_h; hpr.out[k] = W.tn_h + (size_t)k * slab; hpr.out_stride[k] = (size_t)p.NHID * slab;
+    }
+    ReduceJob head_tn_job = {};
+    bool head_tn_pending = false;
     if (p.NHID > 0) {
-        TnProblems pr = {};
+        head_tn_job.partial = W.tn_h; head_tn_job.nP = W.S_h; head_tn_job.ncols = p.NHID * slab;
+        ReduceDst& rd = head_tn_job.rd;
+        rd.n = 2 * p.NHID;
         for (int k = 0; k < p.NHID; ++k) {
-            pr.X[k] = dpre_all + (size_t)k * eh;
-            pr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
+            rd.dst[2 * k] = G[hbase + 2 * k]; rd.dst[2 * k + 1] = G[hbase + 2 * k + 1];
+            rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H;
         }
-        for (int k = 0; k < p.NHID; ++k) {
-            pr.rows[k] = d.Re; pr.nslices[k] = W.S_h; pr.out[k] = W.tn_h + (size_t)k * slab; pr.out_stride[k] = (size_t)p.NHID * slab;
-        }
-        int rc = 0;
-        DISPATCH_MT(d.MT, rc = launch_tn<MT>(H, pr, p.NHID, W.S_h, st));
-        if (rc) return rc;
+        rd.off[2 * p.NHID] = p.NHID * slab;
     }
     {
-        const int wcols = (p.voc * H + p.voc + 3) & ~3;   // per-wavefront stride of wpartial
-        // output-layer gradients, hidden-layer weight gradients and the BatchNorm backward of the top layer
+        const int wcols = (p.voc * H + p.voc + 3) & ~3;   // row stride of wpartial
         ReduceJobs jobs = {};
         jobs.job[0].partial = W.wpartial; jobs.job[0].nP = p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK; jobs.job[0].ncols = wcols;
         jobs.job[0].rd.n = 2; jobs.job[0].rd.dst[0] = G[hbase + 2 * p.NHID]; jobs.job[0].rd.dst[1] = G[hbase + 2 * p.NHID + 1];
         jobs.job[0].rd.off[0] = 0; jobs.job[0].rd.off[1] = p.voc * H; jobs.job[0].rd.off[2] = p.voc * H + p.voc;
-        int maxcols = std::max(wcols, 2 * H);
         jobs.n = 1;
-        if (p.NHID > 0) {
-            jobs.n = 2;
-            jobs.job[1].partial = W.tn_h; jobs.job[1].nP = W.S_h; jobs.job[1].ncols = p.NHID * slab;
-            ReduceDst& rd = jobs.job[1].rd;
-            rd.n = 2 * p.NHID;
-            for (int k = 0; k < p.NHID; ++k) {
-                rd.dst[2 * k] = G[hbase + 2 * k]; rd.dst[2 * k + 1] = G[hbase + 2 * k + 1];
-                rd.off[2 * k] = k * slab; rd.off[2 * k + 1] = k * slab + H * H;
-            }
-            rd.off[2 * p.NHID] = p.NHID * slab;
-            maxcols = std::max(maxcols, p.NHID * slab);
-        }
         float* const* GL = G + 3 + GCN_LAYER_NPARAMS * (p.L - 1);
         bn_finish_job(jobs.job[jobs.n++], W.lw.bpart_e, npart_e, H, (double)d.Re, GL[11], GL[10], W.lw.bstats_e);
         bn_finish_job(jobs.job[jobs.n++], W.lw.bpart_x, npart_x, H, (double)d.Rn, GL[9], GL[8], W.lw.bstats_x);
-        GCN_PROF_PRE("k_reduce_slabs(head)");
-        k_reduce_slabs<<<dim3((maxcols + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
+        if (d.MT <= 4) {
+            WgradMap map = {};
+            int nb = 0;
+            for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += k < p.NHID ? hpr.nslices[k] : 0; }
+            for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < jobs.n) nb += (jobs.job[k].ncols + 15) / 16; }
+            map.seg[8] = nb;
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad(head)", (k_wgrad<MT>), nb, GCN_BLOCK, H, hpr, jobs, map));
+            head_tn_pending = p.NHID > 0;
+        } else {
+            if (p.NHID > 0) {
+                if (int rc = launch_tn<0>(H, hpr, p.NHID, W.S_h, st)) return rc;
+                jobs.job[jobs.n++] = head_tn_job;
+            }
+            int maxcols = 0;
+            for (int k = 0; k < jobs.n; ++k) maxcols = std::max(maxcols, jobs.job[k].ncols);
+            GCN_PROF_PRE("k_reduce_slabs(head)");
+            k_reduce_slabs<<<dim3((maxcols + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
+            GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
+        }
     }
     for (int l = p.L - 1; l >= 0; --l) {
         const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
@@ -943,6 +953,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             bn_finish_job(jobs.job[nj + 1], W.lw.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.lw.bstats_x);
             nj += 2;
         }
+        if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // only in the top layer's launch: nj <= 3
         jobs.n = nj;
         for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += (jobs.job[k].ncols + 15) / 16; }
         map.seg[8] = nb;
