@@ -18,6 +18,7 @@
 #include "kernels_fwd.hpp"
 #include "kernels_strip.hpp"
 #include "kernels_wide.hpp"
+#include "sampler.hpp"
 
 namespace {
 
@@ -1134,6 +1135,64 @@ int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* pa
     GCN_PROF_PRE("k_max_load_factor");
     k_max_load_factor<<<B, 256, 0, st>>>(V, usage_ws, cap, max_lf);
     GCN_CHECK_LAUNCH("k_max_load_factor");
+    return 0;
+}
+
+namespace {
+int sampler_check(const char* who, int B, int V, int C, float temperature) {
+    if (B <= 0 || V <= 0 || C <= 0) return fail(-1, "%s: non-positive dimension", who);
+    if (V > SMP_MAX_V) return fail(-2, "%s: V = %d exceeds the sampler's limit of %d nodes", who, V, SMP_MAX_V);
+    if (!(temperature > 0.f)) return fail(-1, "%s: temperature must be positive", who);
+    if ((size_t)B * V * V * C >= ((size_t)1 << 31)) return fail(-2, "%s: logits tensor too large for 32-bit row indices", who);
+    return 0;
+}
+}  // namespace
+
+int gcn_path_sample(int B, int V, int C, float temperature, float top_p, float eps, const float* y, const float* cap,
+                    const long long* comm, const unsigned long long* rng, int given_paths, int* paths, int* path_len,
+                    float* logp, float* step_entropy, int* n_entropy, void* stream) {
+    if (int rc = sampler_check("gcn_path_sample", B, V, C, temperature)) return rc;
+    if (!y || !cap || !comm || !paths || !path_len || !logp || !step_entropy || !n_entropy)
+        return fail(-1, "gcn_path_sample: null pointer argument");
+    if (!given_paths && !rng) return fail(-1, "gcn_path_sample: rng is required when paths are drawn");
+    SampleArgs a = {};
+    a.B = B; a.V = V; a.C = C; a.PL = std::max(V, 10);
+    a.temperature = temperature; a.top_p = top_p; a.eps = eps;
+    a.y = y; a.cap = cap; a.comm = comm; a.rng = rng;
+    a.paths = paths; a.path_len = path_len; a.logp = logp; a.ent = step_entropy; a.n_ent = n_entropy;
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_path_sample");
+    if (given_paths) k_path_sample<SMP_MODE_EVAL><<<B * C, 64, 0, st>>>(a);
+    else k_path_sample<SMP_MODE_SAMPLE><<<B * C, 64, 0, st>>>(a);
+    GCN_CHECK_LAUNCH("k_path_sample");
+    return 0;
+}
+
+int gcn_path_sample_bwd(int B, int V, int C, float temperature, float eps, const float* y, const float* cap,
+                        const long long* comm, const int* paths, const int* path_len, const float* dlogp, float* dy,
+                        void* stream) {
+    if (int rc = sampler_check("gcn_path_sample_bwd", B, V, C, temperature)) return rc;
+    if (!y || !cap || !comm || !paths || !path_len || !dlogp || !dy) return fail(-1, "gcn_path_sample_bwd: null pointer argument");
+    SampleArgs a = {};
+    a.B = B; a.V = V; a.C = C; a.PL = std::max(V, 10);
+    a.temperature = temperature; a.top_p = 1.f; a.eps = eps;
+    a.y = y; a.cap = cap; a.comm = comm;
+    a.paths = const_cast<int*>(paths); a.path_len = const_cast<int*>(path_len);
+    a.dlogp = dlogp; a.dy = dy;
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_path_sample_bwd");
+    k_path_sample<SMP_MODE_BWD><<<B * C, 64, 0, st>>>(a);
+    GCN_CHECK_LAUNCH("k_path_sample_bwd");
+    return 0;
+}
+
+int gcn_reachability(int B, int V, const float* cap, unsigned char* reach, void* stream) {
+    if (B <= 0 || V <= 0 || !cap || !reach) return fail(-1, "gcn_reachability: bad argument");
+    if (V > SMP_MAX_V) return fail(-2, "gcn_reachability: V = %d exceeds the limit of %d nodes", V, SMP_MAX_V);
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_reachability");
+    k_reachability<<<B * V, 64, 0, st>>>(V, cap, reach);
+    GCN_CHECK_LAUNCH("k_reachability");
     return 0;
 }
 

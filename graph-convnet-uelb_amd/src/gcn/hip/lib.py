@@ -91,6 +91,14 @@ def _declare(lib):
         lib.gcn_load_factor.restype = c_int
         lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_path_sample.restype = c_int
+    lib.gcn_path_sample.argtypes = [c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_path_sample_bwd.restype = c_int
+    lib.gcn_path_sample_bwd.argtypes = [c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_reachability.restype = c_int
+    lib.gcn_reachability.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p]
     if hasattr(lib, "gcn_adam_step"):
         lib.gcn_adam_step.restype = c_int
         lib.gcn_adam_step.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,

@@ -172,6 +172,33 @@ int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* pa
                     const long long* comm, int* usage_ws, float* max_lf, unsigned char* complete, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stochastic path sampling of the REINFORCE training path, batched on the GPU.
+ * Replaces PathSampler.sample / _sample_single_path / _top_p_sample (src/gcn/algorithms/path_sampler.py
+ * :51-214, :272-405, :407-426), the reachability precomputation (:220-260) and, in gcn_path_sample_bwd, what
+ * autograd derives from the returned log-probabilities (src/gcn/training/reinforcement_strategy.py:427-428).
+ *
+ * y [B,V,V,C] fp32 edge scores (voc_out == 1 predictions), cap [B,V,V], comm [B,C,3] int64 (src, dst, demand).
+ * temperature > 0, top_p = nucleus mass, eps = weight of the uniform mixture (0 = none).  V <= 256.
+ * rng: two 64-bit words {seed, call counter} in device memory; the draws are a counter-based function of
+ * (seed, counter, graph, commodity, step), so a call is reproducible and the caller advances the counter.
+ * given_paths == 0: paths are drawn and written; given_paths != 0: paths / path_len are inputs and only their
+ * log-probabilities and entropies are evaluated (rng may be NULL).
+ * Outputs: paths int32 [B,C,PL] padded with -1, PL = max(V, 10); path_len int32 [B,C]; logp float [B,C] (the
+ * reference's per-graph value is the sum over C); step_entropy float [B,C,PL] with n_entropy int32 [B,C] valid
+ * entries per commodity (fallback steps record none).
+ * gcn_path_sample_bwd ADDS d(sum_c logp[b,c]) / d y * dlogp[b] into dy [B,V,V,C]; the caller clears dy or passes
+ * a gradient to accumulate into.  Paths never visit a node twice, so no two additions touch the same element.
+ * gcn_reachability: reach uint8 [B,V,V], reach[b,i,j] = 1 iff j can be reached from i over edges with cap > 0.
+ * ---------------------------------------------------------------------------------------------- */
+int gcn_path_sample(int B, int V, int C, float temperature, float top_p, float eps, const float* y, const float* cap,
+                    const long long* comm, const unsigned long long* rng, int given_paths, int* paths, int* path_len,
+                    float* logp, float* step_entropy, int* n_entropy, void* stream);
+int gcn_path_sample_bwd(int B, int V, int C, float temperature, float eps, const float* y, const float* cap,
+                        const long long* comm, const int* paths, const int* path_len, const float* dlogp, float* dy,
+                        void* stream);
+int gcn_reachability(int B, int V, const float* cap, unsigned char* reach, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam update of n parameter tensors in one or a few launches (multi-tensor).  Replaces the
  * torch.optim.Adam(lr) step of the trainer (src/gcn/train/trainer.py:95,
  * src/gcn/training/supervised_strategy.py:98-100) with the same arithmetic (no amsgrad; weight_decay is the

@@ -5,7 +5,7 @@ Run in the build container only (the reference checkout is not present on the GP
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--ref /root/reference]
 
-It imports the reference's model and beam search unchanged, feeds them seeded synthetic
+It imports the reference's model, beam search and path sampler unchanged, feeds them seeded synthetic
 inputs with the value ranges of the reference's configs, and stores inputs, weights and the
 reference's outputs as .npz files.  Nothing of the reference's source is stored, only data.
 Model cases run in eval mode with autograd on (dropout off; BatchNorm still uses batch
@@ -189,17 +189,105 @@ def run_beam_case(name, B, V, C, K, algorithm, strict, seed, cap_rng=(1000, 5000
     np.savez_compressed(path, **out)
     print(f"{name}: feasible={feas} perms={len(drawn)} -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
 
+# ----------------------------------------------------------------------------- path-sampler cases
+def run_sampler_case(name, B, V, C, temperature, top_p, eps, seed, isolate_dst=False, spike=False, extra_edges=0.2):
+    """Runs the reference's PathSampler once and stores its sampled paths, log-probabilities, step entropies,
+    reachability and the autograd gradient of a fixed linear functional of the log-probabilities."""
+    from src.gcn.algorithms.path_sampler import PathSampler
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cap, comm = make_graph_batch(rng, B, V, C, 1000, 5000, 5, 500, extra_edges)
+    if isolate_dst:
+        # graph 0: the destination of commodity 0 loses all its edges (unreachable -> the path gets stuck)
+        d = comm[0, 0, 1]
+        cap[0, d, :] = 0
+        cap[0, :, d] = 0
+    logits = rng.standard_normal((B, V, V, C)).astype(np.float32) * 2.0
+    if spike:
+        # a few huge logits: rows whose whole mass sits on one edge, so that after masking the rest underflows
+        for _ in range(3 * B * C):
+            b, i, j, c = rng.integers(0, B), rng.integers(0, V), rng.integers(0, V), rng.integers(0, C)
+            logits[b, i, j, c] = 300.0
+    logits[np.broadcast_to((cap == 0)[..., None], logits.shape)] = -1e9         # what the model's own mask does
+    y = torch.from_numpy(logits.copy()).requires_grad_(True)
+    sampler = PathSampler(y_pred_edges=y, edges_capacity=torch.from_numpy(cap), commodities=torch.from_numpy(comm),
+                          num_samples=1, temperature=temperature, top_p=top_p, entropy_epsilon=eps)
+    paths, logp, feasible, ents = sampler.sample()
+    w = rng.standard_normal(B).astype(np.float32)
+    (logp * torch.from_numpy(w)).sum().backward()
+    PL = max(V, 10)
+    parr = -np.ones((B, C, PL), dtype=np.int32)
+    plen = np.zeros((B, C), dtype=np.int32)
+    earr = np.zeros((B, C, PL), dtype=np.float32)
+    nent = np.zeros((B, C), dtype=np.int32)
+    for b in range(B):
+        for c in range(C):
+            p = [int(v) for v in paths[b][c]]
+            parr[b, c, :len(p)] = p
+            plen[b, c] = len(p)
+            earr[b, c, :len(ents[b][c])] = ents[b][c]
+            nent[b, c] = len(ents[b][c])
+    out = dict(cfg_B=B, cfg_V=V, cfg_C=C, cfg_temperature=np.float32(temperature), cfg_top_p=np.float32(top_p),
+               cfg_eps=np.float32(eps), in_logits=logits, in_cap=cap, in_comm=comm, in_w=w, out_paths=parr,
+               out_path_len=plen, out_logp=logp.detach().numpy(), out_feasible=np.int32(bool(feasible)),
+               out_entropy=earr, out_n_entropy=nent, out_dlogits=y.grad.numpy().copy(),
+               out_reach=sampler.reachability.numpy().astype(np.uint8))
+    path = os.path.join(OUT, f"sampler_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"sampler_{name}: logp={logp.detach().numpy().round(3)} feasible={feasible} -> {path} "
+          f"({os.path.getsize(path) / 1e3:.1f} kB)")
+
+
+def run_sampler_freq_case(name, V, temperature, top_p, eps, seed, draws):
+    """First-hop frequencies of the reference's sampler over many draws on one graph with one commodity."""
+    from src.gcn.algorithms.path_sampler import PathSampler
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cap, comm = make_graph_batch(rng, 1, V, 1, 1000, 5000, 5, 500, 0.5)
+    logits = rng.standard_normal((1, V, V, 1)).astype(np.float32)
+    logits[np.broadcast_to((cap == 0)[..., None], logits.shape)] = -1e9
+    counts = np.zeros(V, dtype=np.int64)
+    y = torch.from_numpy(logits.copy())
+    for _ in range(draws):
+        sampler = PathSampler(y_pred_edges=y, edges_capacity=torch.from_numpy(cap), commodities=torch.from_numpy(comm),
+                              num_samples=1, temperature=temperature, top_p=top_p, entropy_epsilon=eps)
+        paths, _, _, _ = sampler.sample()
+        counts[int(paths[0][0][1])] += 1
+    out = dict(cfg_V=V, cfg_temperature=np.float32(temperature), cfg_top_p=np.float32(top_p), cfg_eps=np.float32(eps),
+               cfg_draws=draws, in_logits=logits, in_cap=cap, in_comm=comm, out_first_hop_counts=counts)
+    path = os.path.join(OUT, f"sampler_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"sampler_{name}: counts={counts.tolist()} -> {path}")
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma-separated groups to regenerate: model, beam, sampler (default all)")
     args = ap.parse_args()
+    groups = set(args.only.split(",")) if args.only else {"model", "beam", "sampler"}
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
     os.chdir(args.ref)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
 
+    if "sampler" in groups:
+        run_sampler_case("greedy", 3, 9, 4, 1.0, 1e-6, 0.05, seed=31)
+        run_sampler_case("nsf", 3, 14, 5, 1.3, 0.9, 0.05, seed=32)
+        run_sampler_case("noeps_stuck", 2, 10, 4, 0.8, 0.95, 0.0, seed=33, isolate_dst=True)
+        run_sampler_case("spike", 3, 8, 4, 1.0, 0.9, 0.05, seed=34, spike=True, extra_edges=0.5)
+        run_sampler_case("v70", 1, 70, 3, 1.5, 0.95, 0.05, seed=35, extra_edges=0.05)
+        run_sampler_freq_case("freq", 8, 1.2, 0.85, 0.05, seed=36, draws=4000)
+    if "model" in groups:
+        run_model_cases()
+    if "beam" in groups:
+        run_beam_cases()
+
+
+def run_model_cases():
     run_model_case("tiny", 2, 5, 3, 8, 2, seed=1)
     run_model_case("h12_mlp3", 2, 6, 4, 12, 2, mlp_layers=3, seed=2)
     run_model_case("sum_agg", 2, 5, 3, 8, 2, aggregation="sum", seed=3)
@@ -208,6 +296,8 @@ def main():
     run_model_case("wide", 2, 40, 5, 64, 1, seed=6, keep_layers=False)
     run_model_case("h32_l3", 2, 7, 2, 32, 3, seed=7)
 
+
+def run_beam_cases():
     run_beam_case("det_strict", 4, 14, 10, 10, "deterministic", True, seed=11)
     run_beam_case("det_loose", 3, 10, 5, 3, "deterministic", False, seed=12)
     run_beam_case("std_strict", 4, 14, 10, 5, "standard", True, seed=13)
