@@ -1196,6 +1196,34 @@ int gcn_reachability(int B, int V, const float* cap, unsigned char* reach, void*
     return 0;
 }
 
+int gcn_entropy_grid_fwd(int B, int V, int C, float temperature, const float* y, float* row_ws, float* out, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || !y || !row_ws || !out) return fail(-1, "gcn_entropy_grid_fwd: bad argument");
+    if (!(temperature > 0.f)) return fail(-1, "gcn_entropy_grid_fwd: temperature must be positive");
+    if ((size_t)B * V * V * C >= ((size_t)1 << 31)) return fail(-2, "gcn_entropy_grid_fwd: logits tensor too large");
+    const int rows = B * V * C;
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_entropy_rows");
+    k_entropy_rows<<<(rows + 255) / 256, 256, 0, st>>>(rows, V, C, temperature, y, row_ws);
+    GCN_CHECK_LAUNCH("k_entropy_rows");
+    GCN_PROF_PRE("k_entropy_finish");
+    k_entropy_finish<<<1, 256, 0, st>>>(rows, row_ws, out);
+    GCN_CHECK_LAUNCH("k_entropy_finish");
+    return 0;
+}
+
+int gcn_entropy_grid_bwd(int B, int V, int C, float temperature, const float* y, const float* row_ws, const float* out,
+                         const float* dout, float* dy, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || !y || !row_ws || !out || !dy) return fail(-1, "gcn_entropy_grid_bwd: bad argument");
+    if (!(temperature > 0.f)) return fail(-1, "gcn_entropy_grid_bwd: temperature must be positive");
+    if ((size_t)B * V * V * C >= ((size_t)1 << 31)) return fail(-2, "gcn_entropy_grid_bwd: logits tensor too large");
+    const int rows = B * V * C;
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_entropy_bwd");
+    k_entropy_bwd<<<(rows + 255) / 256, 256, 0, st>>>(rows, V, C, temperature, y, row_ws, out, dout, dy);
+    GCN_CHECK_LAUNCH("k_entropy_bwd");
+    return 0;
+}
+
 int gcn_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
                   float weight_decay, long long step, void* stream) {

@@ -314,3 +314,82 @@ __global__ __launch_bounds__(64) void k_reachability(int V, const float* __restr
         if (j < V) reach[((size_t)b * V + j) * V + dst] = (unsigned char)((R[i] >> lane) & 1);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Entropy of the next-node distribution of every (graph, node, commodity) row, the exploration bonus of the
+// REINFORCE loss (src/gcn/training/reinforcement_strategy.py:460-476, :494):
+//   p = softmax(y / T over j), H_row = -sum_j p log p, multi_row = (#{j: p > 1e-8} >= 2),
+//   entropy = mean of H_row over the rows with multi_row (over all rows if there is none).
+// k_entropy_rows: one thread per row (rows are contiguous in c, so a wavefront reads contiguous logits for each
+// j).  row_ws[r] = H_row, row_ws[rows + r] = multi_row.  k_entropy_finish reduces in a fixed order:
+// out = {entropy, number of rows averaged, 1 if only multi rows were averaged, 0}.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_entropy_rows(int rows, int V, int C, float temperature, const float* __restrict__ y,
+                                                      float* __restrict__ row_ws) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const int bi = r / C, c = r % C;
+    const float* yr = y + (size_t)bi * V * C + c;
+    float zmax = -INFINITY;
+    for (int j = 0; j < V; ++j) zmax = fmaxf(zmax, yr[(size_t)j * C] / temperature);
+    float se = 0.f;
+    for (int j = 0; j < V; ++j) se += expf(yr[(size_t)j * C] / temperature - zmax);
+    const float lse = logf(se);
+    float H = 0.f;
+    int n = 0;
+    for (int j = 0; j < V; ++j) {
+        const float lp = yr[(size_t)j * C] / temperature - zmax - lse;
+        const float p = expf(yr[(size_t)j * C] / temperature - zmax) / se;
+        H -= p * lp;
+        n += p > 1e-8f ? 1 : 0;
+    }
+    row_ws[r] = H;
+    row_ws[rows + r] = n >= 2 ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_entropy_finish(int rows, const float* __restrict__ row_ws, float* __restrict__ out) {
+    __shared__ double sm[256], sa[256];
+    __shared__ int cm[256];
+    double m = 0.0, a = 0.0;
+    int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float H = row_ws[r];
+        a += H;
+        if (row_ws[rows + r] != 0.f) { m += H; ++n; }
+    }
+    sm[threadIdx.x] = m; sa[threadIdx.x] = a; cm[threadIdx.x] = n;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { sm[threadIdx.x] += sm[threadIdx.x + s]; sa[threadIdx.x] += sa[threadIdx.x + s]; cm[threadIdx.x] += cm[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool multi = cm[0] > 0;
+        const int cnt = multi ? cm[0] : rows;
+        out[0] = (float)((multi ? sm[0] : sa[0]) / (double)cnt);
+        out[1] = (float)cnt; out[2] = multi ? 1.f : 0.f; out[3] = 0.f;
+    }
+}
+
+// dy[b,i,j,c] += dout / count * (-p_j (log p_j + H_row)) / T for the rows that were averaged
+__global__ __launch_bounds__(256) void k_entropy_bwd(int rows, int V, int C, float temperature, const float* __restrict__ y,
+                                                     const float* __restrict__ row_ws, const float* __restrict__ out,
+                                                     const float* __restrict__ dout, float* __restrict__ dy) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    if (out[2] != 0.f && row_ws[rows + r] == 0.f) return;
+    const int bi = r / C, c = r % C;
+    const float* yr = y + (size_t)bi * V * C + c;
+    float* dr = dy + (size_t)bi * V * C + c;
+    const float g = (dout ? dout[0] : 1.f) / out[1] / temperature, H = row_ws[r];
+    float zmax = -INFINITY;
+    for (int j = 0; j < V; ++j) zmax = fmaxf(zmax, yr[(size_t)j * C] / temperature);
+    float se = 0.f;
+    for (int j = 0; j < V; ++j) se += expf(yr[(size_t)j * C] / temperature - zmax);
+    const float lse = logf(se);
+    for (int j = 0; j < V; ++j) {
+        const float z = yr[(size_t)j * C] / temperature - zmax;
+        const float p = expf(z) / se;
+        dr[(size_t)j * C] += -g * p * ((z - lse) + H);
+    }
+}

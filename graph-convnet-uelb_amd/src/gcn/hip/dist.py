@@ -45,3 +45,19 @@ def allreduce_mean_(flat, group=None):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.mul_(1.0 / w)
     return flat
+
+
+def allreduce_mean_grads(params, group=None):
+    """Mean over ranks of the .grad tensors of params, as one all-reduce of their concatenation (for steps that
+    go through autograd and therefore have no flat gradient buffer)."""
+    if world() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    allreduce_mean_(flat, group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()

@@ -99,6 +99,11 @@ def _declare(lib):
                                         c_void_p, c_void_p, c_void_p, c_void_p]
     lib.gcn_reachability.restype = c_int
     lib.gcn_reachability.argtypes = [c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.gcn_entropy_grid_fwd.restype = c_int
+    lib.gcn_entropy_grid_fwd.argtypes = [c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_entropy_grid_bwd.restype = c_int
+    lib.gcn_entropy_grid_bwd.argtypes = [c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]
     if hasattr(lib, "gcn_adam_step"):
         lib.gcn_adam_step.restype = c_int
         lib.gcn_adam_step.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,

@@ -25,6 +25,7 @@ from ..hip.fused_adam import FusedAdam
 from ..hip.train_step import HipTrainStep
 from ..models.gcn_model import ResidualGatedGCNModel
 from ..models.model_utils import update_learning_rate
+from ..training.reinforcement_strategy import ReinforcementLearningStrategy
 from ..training.supervised_strategy import SupervisedLearningStrategy
 
 
@@ -40,10 +41,19 @@ class Trainer:
         # the reference builds torch.optim.Adam(lr) here (trainer.py:95); same arithmetic and state layout, one launch per step
         self.optimizer = FusedAdam(self.net.parameters(), lr=config.learning_rate)
         strategy_type = config.get('training_strategy', 'supervised')
-        if strategy_type != 'supervised':
-            raise ValueError(f"training strategy {strategy_type!r} is not available in this build (supervised only)")
-        self.strategy = SupervisedLearningStrategy(config)
+        if strategy_type == 'supervised':
+            self.strategy = SupervisedLearningStrategy(config)
+        elif strategy_type == 'reinforcement':
+            self.strategy = ReinforcementLearningStrategy(config)
+        else:
+            raise ValueError(f"Unknown training strategy: {strategy_type}")
         self._fast = None
+        # steps that go through autograd (accumulation, REINFORCE) average their gradients over the ranks right
+        # before the optimizer step; the graph-replay step reduces its flat gradient buffer itself
+        self._sync_grads = False
+        params = list(self.net.parameters())
+        self.optimizer.register_step_pre_hook(
+            lambda opt, args, kwargs: D.allreduce_mean_grads(params) if self._sync_grads else None)
 
     # ------------------------------------------------------------------ one epoch
     def train_one_epoch(self, master_bar=None):
@@ -56,7 +66,8 @@ class Trainer:
         running_loss = running_err = 0.0
         running_nb = 0
         world, rank = D.world(), D.rank()
-        use_fast = acc == 1
+        use_fast = acc == 1 and isinstance(self.strategy, SupervisedLearningStrategy)
+        rl_sums, rl_n = {}, 0
         for batch_num, batch in enumerate(dataset):
             lo, hi = D.shard_bounds(batch_size, rank, world)
             if use_fast:
@@ -77,14 +88,25 @@ class Trainer:
                 sub = type(batch)({k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == batch_size else v) for k, v in batch.items()})
                 data = self.strategy.prepare_batch_data(sub, self.device)
                 loss, metrics = self.strategy.compute_loss(self.net, data, self.device)
+                self._sync_grads = True
                 self.strategy.backward_step(loss, self.optimizer, acc, batch_num)
+                self._sync_grads = False
                 loss_val, err_val = float(loss.item()), metrics.get('edge_error', 0.0)
+                if 'reward' in metrics:                  # epoch means of the scalar REINFORCE metrics
+                    rl_n += 1
+                    for k, v in metrics.items():
+                        if isinstance(v, (int, float)) and not isinstance(v, bool):
+                            rl_sums[k] = rl_sums.get(k, 0.0) + float(v)
             running_nb += batch_size
             running_loss += batch_size * loss_val
             running_err += batch_size * err_val
         loss = running_loss / max(running_nb, 1)
         err = running_err / max(running_nb, 1)
-        return time.time() - start, loss, err, {}
+        rl_metrics = {k: v / rl_n for k, v in rl_sums.items()} if rl_n else {}
+        if rl_n:
+            rl_metrics['load_factor'] = rl_metrics.get('avg_finite_load_factor', 0.0)
+            rl_metrics['baseline'] = self.strategy.reward_baseline or 0.0
+        return time.time() - start, loss, err, rl_metrics
 
     # ------------------------------------------------------------------ accessors / checkpoints
     def get_model(self):
@@ -124,13 +146,18 @@ class Trainer:
         lr = cfg.learning_rate
         history = []
         for epoch in range(cfg.max_epochs):
-            t, loss, err, _ = self.train_one_epoch()
+            if hasattr(self.strategy, 'set_epoch'):
+                self.strategy.set_epoch(epoch)
+            t, loss, err, rl = self.train_one_epoch()
             line = f"epoch {epoch + 1}/{cfg.max_epochs}  time {t:.2f}s  lr {lr:.2e}  loss {loss:.4f}  err_edges {err:.2f}"
             if evaluator is not None and (epoch + 1) % cfg.get('val_every', 1) == 0:
                 res = evaluator.evaluate(self.net, None, mode='val')
                 line += f"  val_loss {res[1]:.4f}  val_load_factor {res[2]:.4f}  infeasible% {res[5]:.1f}"
                 lr /= cfg.get('decay_rate', 1.0)
                 self.update_learning_rate(lr)
+            if rl:
+                line += (f"  reward {rl['reward']:.4f}  entropy {rl.get('entropy', 0):.4f}  complete% {rl.get('complete_paths_rate', 0):.1f}"
+                         f"  T {rl.get('temperature', 0):.2f}")
             if D.rank() == 0:
                 print(line, flush=True)
             history.append((epoch + 1, t, loss, err))

@@ -199,6 +199,19 @@ int gcn_path_sample_bwd(int B, int V, int C, float temperature, float eps, const
 int gcn_reachability(int B, int V, const float* cap, unsigned char* reach, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Entropy bonus of the REINFORCE loss: mean entropy of the next-node distributions softmax(y / T over j) of
+ * the (graph, node, commodity) rows that have at least two entries above 1e-8 (all rows if there is none).
+ * Replaces the entropy_grid computation of ReinforcementLearningStrategy.compute_loss
+ * (src/gcn/training/reinforcement_strategy.py:460-476) and its autograd backward.
+ * y [B,V,V,C]; row_ws: 2*B*V*C floats kept from forward to backward; out float[4] = {entropy, rows averaged,
+ * 1 if only multi-choice rows were averaged, 0}.  gcn_entropy_grid_bwd ADDS dout[0] * d entropy / d y into dy
+ * (dout NULL = 1).
+ * ---------------------------------------------------------------------------------------------- */
+int gcn_entropy_grid_fwd(int B, int V, int C, float temperature, const float* y, float* row_ws, float* out, void* stream);
+int gcn_entropy_grid_bwd(int B, int V, int C, float temperature, const float* y, const float* row_ws, const float* out,
+                         const float* dout, float* dy, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam update of n parameter tensors in one or a few launches (multi-tensor).  Replaces the
  * torch.optim.Adam(lr) step of the trainer (src/gcn/train/trainer.py:95,
  * src/gcn/training/supervised_strategy.py:98-100) with the same arithmetic (no amsgrad; weight_decay is the

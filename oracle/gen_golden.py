@@ -261,13 +261,74 @@ def run_sampler_freq_case(name, V, temperature, top_p, eps, seed, draws):
     np.savez_compressed(path, **out)
     print(f"sampler_{name}: counts={counts.tolist()} -> {path}")
 
+def run_rl_loss_case(name, B, V, C, seed, calls=2, tight=False, **rl):
+    """Runs the reference's ReinforcementLearningStrategy.compute_loss on fixed edge scores (a stub model returns
+    them, masked like the real model) `calls` times in a row, so that the moving baseline is exercised, and stores
+    the sampled paths, rewards, advantages, loss terms and d loss / d scores of every call."""
+    from src.gcn.training.reinforcement_strategy import ReinforcementLearningStrategy
+
+    class FixedScores(torch.nn.Module):
+        def __init__(self, y):
+            super().__init__()
+            self.y = torch.nn.Parameter(y)
+
+        def forward(self, x_edges, x_commodities, cap, x_nodes, y_edges=None, edge_cw=None, compute_loss=False,
+                    mask_invalid_edges=False):
+            y = self.y
+            if mask_invalid_edges:
+                y = y.masked_fill((cap.unsqueeze(-1) == 0).expand_as(y), -1e9)
+            return y, None
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    cfg = dict(batch_size=B, num_nodes=V, num_commodities=C, rl_debug_logging=False, **rl)
+    strat = ReinforcementLearningStrategy(cfg)
+    out = dict(cfg_B=B, cfg_V=V, cfg_C=C, cfg_calls=calls, cfg_json=np.asarray(__import__("json").dumps(cfg)))
+    PL = max(V, 10)
+    for k in range(calls):
+        if tight:
+            cap, comm = make_graph_batch(rng, B, V, C, 300, 700, 100, 500, 0.3)
+        else:
+            cap, comm = make_graph_batch(rng, B, V, C, 1000, 5000, 5, 500, 0.2)
+        logits = rng.standard_normal((B, V, V, C)).astype(np.float32) * 1.5
+        model = FixedScores(torch.from_numpy(logits.copy()))
+        model.train()
+        strat.set_epoch(k)
+        data = dict(x_edges=torch.from_numpy((cap > 0).astype(np.int64)), x_commodities=torch.from_numpy(comm[:, :, 2].astype(np.float32)),
+                    x_edges_capacity=torch.from_numpy(cap), x_nodes=torch.from_numpy(nodes_from_commodities(comm, V)),
+                    batch_commodities=torch.from_numpy(comm))
+        loss, m = strat.compute_loss(model, data)
+        loss.backward()
+        parr = -np.ones((B, C, PL), dtype=np.int32)
+        plen = np.zeros((B, C), dtype=np.int32)
+        for b in range(B):
+            for c in range(C):
+                p = [int(v) for v in m['pred_paths'][b][c]]
+                parr[b, c, :len(p)] = p
+                plen[b, c] = len(p)
+        pre = f"call{k}."
+        out.update({pre + "in_logits": logits, pre + "in_cap": cap, pre + "in_comm": comm, pre + "paths": parr,
+                    pre + "path_len": plen, pre + "loss": np.float32(loss.item()), pre + "dlogits": model.y.grad.numpy().copy()})
+        for key in ("reward_individual", "advantage_individual", "load_factor_individual"):
+            out[pre + key] = np.asarray(m[key], dtype=np.float32)
+        for key in ("entropy", "traj_entropy", "entropy_used", "policy_loss", "entropy_bonus", "baseline_before_update",
+                    "baseline_after_update", "complete_paths_rate", "finite_solution_rate", "avg_finite_load_factor",
+                    "avg_path_length", "capacity_violation_rate", "temperature", "reward", "reward_std", "advantage_std"):
+            out[pre + key] = np.float64(m[key])
+        out[pre + "fallback"] = np.int32(bool(m["reinforce_fallback_used"]))
+        print(f"rl_{name} call {k}: loss={loss.item():.5f} rewards={np.round(m['reward_individual'], 3).tolist()} "
+              f"entropy={m['entropy']:.4f} T={m['temperature']}")
+    path = os.path.join(OUT, f"rl_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"rl_{name} -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="comma-separated groups to regenerate: model, beam, sampler (default all)")
+    ap.add_argument("--only", default="", help="comma-separated groups to regenerate: model, beam, sampler, rl (default all)")
     args = ap.parse_args()
-    groups = set(args.only.split(",")) if args.only else {"model", "beam", "sampler"}
+    groups = set(args.only.split(",")) if args.only else {"model", "beam", "sampler", "rl"}
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
     os.chdir(args.ref)
@@ -281,6 +342,12 @@ def main():
         run_sampler_case("spike", 3, 8, 4, 1.0, 0.9, 0.05, seed=34, spike=True, extra_edges=0.5)
         run_sampler_case("v70", 1, 70, 3, 1.5, 0.95, 0.05, seed=35, extra_edges=0.05)
         run_sampler_freq_case("freq", 8, 1.2, 0.85, 0.05, seed=36, draws=4000)
+    if "rl" in groups:
+        run_rl_loss_case("default", 4, 9, 4, seed=41, rl_sampling_temperature=1.5, rl_min_temperature=0.8,
+                         rl_temperature_decay=0.035, rl_sampling_top_p=0.95, rl_entropy_weight=0.1, rl_entropy_epsilon=0.05,
+                         rl_baseline_momentum=0.95)
+        run_rl_loss_case("tight", 5, 8, 6, seed=42, calls=3, tight=True, rl_sampling_top_p=0.9, rl_entropy_weight=0.01,
+                         rl_entropy_epsilon=0.0, rl_normalize_advantages=False)
     if "model" in groups:
         run_model_cases()
     if "beam" in groups:

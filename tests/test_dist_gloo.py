@@ -42,6 +42,13 @@ def _worker(rank, world, port, out):
         want = torch.arange(10, dtype=torch.float32) * (1 + 2) / 2
         assert torch.allclose(flat, want)
         assert torch.allclose(views[0], want[:4].view(2, 2))                # p.grad views see the reduced values
+        # per-parameter gradients of an autograd step: averaged through one concatenated message
+        q = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(1))]
+        q[0].grad = torch.full((3,), float(rank))
+        q[1].grad = torch.full((2, 2), 2.0 * rank + 1.0)
+        D.allreduce_mean_grads(q)
+        assert torch.allclose(q[0].grad, torch.full((3,), 0.5)) and torch.allclose(q[1].grad, torch.full((2, 2), 2.0))
+        assert q[2].grad is None
         out.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         out.put((rank, repr(ex)))
