@@ -19,6 +19,7 @@
 #include "kernels_strip.hpp"
 #include "kernels_wide.hpp"
 #include "sampler.hpp"
+#include "dataset.hpp"
 
 namespace {
 
@@ -1221,6 +1222,29 @@ int gcn_entropy_grid_bwd(int B, int V, int C, float temperature, const float* y,
     GCN_PROF_PRE("k_entropy_bwd");
     k_entropy_bwd<<<(rows + 255) / 256, 256, 0, st>>>(rows, V, C, temperature, y, row_ws, out, dout, dy);
     GCN_CHECK_LAUNCH("k_entropy_bwd");
+    return 0;
+}
+
+int gcn_unpack_batch(int B, int V, int C, const unsigned char* edges_u8, const int* comm_i32, const short* flow_i16,
+                     long long* x_edges, long long* x_nodes, long long* y_edges, long long* comm, float* demand,
+                     short* succ_ws, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0) return fail(-1, "gcn_unpack_batch: non-positive dimension");
+    if (V > 32767) return fail(-2, "gcn_unpack_batch: V = %d does not fit the 16-bit node order", V);
+    if (!edges_u8 || !comm_i32 || !flow_i16 || !x_edges || !x_nodes || !y_edges || !comm || !demand || !succ_ws)
+        return fail(-1, "gcn_unpack_batch: null pointer argument");
+    // every output must be no larger than y_edges, whose index range the fill kernel walks: V >= 3 / C covers comm
+    if ((size_t)V * V < 3) return fail(-2, "gcn_unpack_batch: needs V >= 2");
+    if ((size_t)B * C * V >= ((size_t)1 << 31)) return fail(-2, "gcn_unpack_batch: batch too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = B * C * V;
+    GCN_PROF_PRE("k_unpack_succ");
+    k_unpack_succ<<<(n + 255) / 256, 256, 0, st>>>(n, V, flow_i16, succ_ws);
+    GCN_CHECK_LAUNCH("k_unpack_succ");
+    UnpackArgs a = {B, V, C, edges_u8, comm_i32, succ_ws, x_edges, x_nodes, y_edges, comm, demand};
+    const size_t ny = (size_t)B * V * V * C;
+    GCN_PROF_PRE("k_unpack_fill");
+    k_unpack_fill<<<(int)std::min<size_t>((ny + 255) / 256, 4096), 256, 0, st>>>(a);
+    GCN_CHECK_LAUNCH("k_unpack_fill");
     return 0;
 }
 

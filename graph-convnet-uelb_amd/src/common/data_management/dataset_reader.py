@@ -19,7 +19,7 @@ import numpy as np
 
 from ..synthetic import make_batch
 
-BUCKET_SIZE = 1000
+BUCKET_SIZE = 10          # samples per numbered sub-directory (reference src/common/config/paths.py:30)
 
 
 class DotDict(dict):
@@ -28,9 +28,64 @@ class DotDict(dict):
 
 
 def data_dir_for(config, mode):
-    root = os.environ.get("GCN_UELB_DATA_ROOT", str(Path(config.get("data_root", "../ml-data")).expanduser()))
-    name = config.get("dataset_name", config.get("expt_name", "default"))
-    return Path(root) / name / f"{mode}_data"
+    """<data root>/<dataset name>/<mode>_data; the root comes from $GCN_UELB_DATA_ROOT, then config.data_root, then
+    ../ml-data/graph-convnet-uelb/datasets (reference src/common/config/paths.py:54-99)."""
+    root = os.environ.get("GCN_UELB_DATA_ROOT") or config.get("data_root") or "../ml-data/graph-convnet-uelb/datasets"
+    name = config.get("dataset_name") or config.get("expt_name")
+    if not name:
+        raise ValueError("Config must specify 'dataset_name' (or 'expt_name' as fallback) to locate the dataset directory.")
+    return Path(str(root)).expanduser() / str(name) / f"{mode}_data"
+
+
+def read_exact_solutions(data_dir):
+    """First column of exact_solution.csv, one row per sample in index order, or None if the file is absent
+    (reference dataset_reader.py:46-57)."""
+    f = Path(data_dir) / "exact_solution.csv"
+    if not f.exists():
+        return None
+    with open(f) as fh:
+        return [float(row[0]) for row in csv.reader(fh)]
+
+
+def read_sample(data_dir, i):
+    """One sample of the reference's on-disk layout -> (adjacency [V,V] int, capacity [V,V] float64,
+    commodities [C][3] int, node order [C][V] int) (reference dataset_reader.py:82-127)."""
+    import networkx as nx
+    data_dir = Path(data_dir)
+    bucket = i - (i % BUCKET_SIZE)
+    G = nx.read_gml(str(data_dir / "graph_file" / str(bucket) / f"graph_{i}.gml"), destringizer=int)
+    V = len(G.nodes)
+    with open(data_dir / "commodity_file" / str(bucket) / f"commodity_data_{i}.csv") as f:
+        commodity_list = [[int(r[0]), int(r[1]), int(r[2])] for r in csv.reader(f)]
+    cap = np.zeros((V, V))
+    for u, v, data in G.edges(data=True):
+        cap[u, v] = data.get("capacity", 0)
+    with open(data_dir / "node_flow_file" / str(bucket) / f"node_flow_{i}.csv", newline="") as f:
+        node_flow = [[int(x) for x in row] for row in csv.reader(f)]
+    return nx.adjacency_matrix(G).toarray(), cap, commodity_list, node_flow
+
+
+def nodes_from_commodities(commodity_list, V):
+    """nodes[src, c] = 1, nodes[dst, c] = 2 (reference dataset_reader.py:117-123)."""
+    nodes = np.zeros((V, len(commodity_list)), dtype=int)
+    for c, (s, t, _) in enumerate(commodity_list):
+        nodes[s, c] = 1
+        nodes[t, c] = 2
+    return nodes
+
+
+def edges_from_node_order(node_flow, V):
+    """target[u, v, c] = 1 for consecutive nodes u, v of commodity c's path, the path being the nodes with a
+    positive visiting order sorted by that order (reference dataset_reader.py:132-145)."""
+    C = len(node_flow)
+    target = np.zeros((V, V, C), dtype=int)
+    for c in range(C):
+        order = np.asarray(node_flow[c])
+        visited = np.nonzero(order > 0)[0]
+        seq = visited[np.argsort(order[visited], kind="stable")]
+        for u, v in zip(seq[:-1], seq[1:]):
+            target[u, v, c] = 1
+    return target
 
 
 class DatasetReader:
@@ -39,13 +94,16 @@ class DatasetReader:
         self.max_iter = num_data // batch_size
         self.shuffle = (mode == "train") if shuffle is None else shuffle
         self.seed = seed
-        self.data_dir = data_dir_for(config, mode)
-        self.synthetic = bool(config.get("synthetic_data", False)) or (
-            not self.data_dir.exists() and bool(config.get("allow_synthetic_data", False)))
+        self.synthetic = bool(config.get("synthetic_data", False))
+        self.data_dir = None
+        if not self.synthetic:
+            self.data_dir = data_dir_for(config, mode)
+            self.synthetic = not self.data_dir.exists() and bool(config.get("allow_synthetic_data", False))
         if not self.synthetic and not self.data_dir.exists():
             raise FileNotFoundError(f"dataset directory {self.data_dir} not found (set GCN_UELB_DATA_ROOT, or "
                                     f"synthetic_data=true in the config)")
         self._epoch = 0
+        self._load_factors = None
 
     def __iter__(self):
         rng = np.random.default_rng(self.seed)
@@ -72,33 +130,12 @@ class DatasetReader:
     def process_batch(self, batch_indices):
         if self.synthetic:
             return self._synthetic_batch(batch_indices)
-        import networkx as nx
         edges, caps, targets, nodes_l, node_targets, comms = [], [], [], [], [], []
         for i in batch_indices:
-            bucket = i - (i % BUCKET_SIZE)
-            G = nx.read_gml(str(self.data_dir / "graph_file" / str(bucket) / f"graph_{i}.gml"), destringizer=int)
-            V = len(G.nodes)
-            with open(self.data_dir / "commodity_file" / str(bucket) / f"commodity_data_{i}.csv") as f:
-                commodity_list = [[int(r[0]), int(r[1]), int(r[2])] for r in csv.reader(f)]
-            C = len(commodity_list)
-            cap = np.zeros((V, V))
-            for u, v, data in G.edges(data=True):
-                cap[u, v] = data.get("capacity", 0)
-            nodes = np.zeros((V, C), dtype=int)
-            for c, (s, t, _) in enumerate(commodity_list):
-                nodes[s, c] = 1
-                nodes[t, c] = 2
-            with open(self.data_dir / "node_flow_file" / str(bucket) / f"node_flow_{i}.csv", newline="") as f:
-                node_flow = [[int(x) for x in row] for row in csv.reader(f)]
-            target = np.zeros((V, V, C), dtype=int)
-            for c in range(C):
-                order = np.asarray(node_flow[c])
-                visited = np.nonzero(order > 0)[0]
-                seq = visited[np.argsort(order[visited], kind="stable")]
-                for u, v in zip(seq[:-1], seq[1:]):
-                    target[u, v, c] = 1
-            edges.append(nx.adjacency_matrix(G).toarray()); caps.append(cap); targets.append(target)
-            nodes_l.append(nodes); node_targets.append(node_flow); comms.append(commodity_list)
+            adj, cap, commodity_list, node_flow = read_sample(self.data_dir, int(i))
+            V = cap.shape[0]
+            edges.append(adj); caps.append(cap); targets.append(edges_from_node_order(node_flow, V))
+            nodes_l.append(nodes_from_commodities(commodity_list, V)); node_targets.append(node_flow); comms.append(commodity_list)
         batch = DotDict()
         batch.edges = np.stack(edges)
         batch.edges_capacity = np.stack(caps)
@@ -106,10 +143,8 @@ class DatasetReader:
         batch.nodes = np.stack(nodes_l)
         batch.nodes_target = np.stack(node_targets)
         batch.commodities = np.stack(comms)
-        batch.load_factor = np.full(len(batch_indices), np.nan)
-        lf_file = self.data_dir / "exact_solution.csv"
-        if lf_file.exists():
-            with open(lf_file) as f:
-                table = {int(r[0]): float(r[1]) for r in csv.reader(f) if r and r[0].strip().lstrip("-").isdigit()}
-            batch.load_factor = np.asarray([table.get(int(i), np.nan) for i in batch_indices])
+        if self._load_factors is None:
+            self._load_factors = read_exact_solutions(self.data_dir) or []
+        batch.load_factor = (np.asarray([self._load_factors[int(i)] for i in batch_indices]) if self._load_factors
+                             else np.full(len(batch_indices), np.nan))
         return batch

@@ -104,6 +104,8 @@ def _declare(lib):
     lib.gcn_entropy_grid_bwd.restype = c_int
     lib.gcn_entropy_grid_bwd.argtypes = [c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p]
+    lib.gcn_unpack_batch.restype = c_int
+    lib.gcn_unpack_batch.argtypes = [c_int, c_int, c_int] + [c_void_p] * 10
     if hasattr(lib, "gcn_adam_step"):
         lib.gcn_adam_step.restype = c_int
         lib.gcn_adam_step.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float,

@@ -48,6 +48,7 @@ class Trainer:
         else:
             raise ValueError(f"Unknown training strategy: {strategy_type}")
         self._fast = None
+        self._packed = None
         # steps that go through autograd (accumulation, REINFORCE) average their gradients over the ranks right
         # before the optimizer step; the graph-replay step reduces its flat gradient buffer itself
         self._sync_grads = False
@@ -60,12 +61,16 @@ class Trainer:
         self.net.train()
         cfg = self.config
         batch_size, acc = cfg.batch_size, cfg.get('accumulation_steps', 1)
-        dataset = DatasetReader(cfg.get('num_train_data'), batch_size, "train", cfg)
+        world, rank = D.world(), D.rank()
+        packed = bool(cfg.get('packed_dataset', False)) and not cfg.get('synthetic_data', False)
+        if packed:
+            dataset = self._packed_train_loader()
+        else:
+            dataset = DatasetReader(cfg.get('num_train_data'), batch_size, "train", cfg)
         self.strategy.reset_metrics()
         start = time.time()
         running_loss = running_err = 0.0
         running_nb = 0
-        world, rank = D.world(), D.rank()
         use_fast = acc == 1 and isinstance(self.strategy, SupervisedLearningStrategy)
         rl_sums, rl_n = {}, 0
         for batch_num, batch in enumerate(dataset):
@@ -73,20 +78,32 @@ class Trainer:
             if use_fast:
                 if self._fast is None or self._fast.B != hi - lo:
                     self._fast = HipTrainStep(self.net, hi - lo, self.device)
-                if self.strategy.edge_cw is None:       # global class weights from the first batch of the epoch
-                    labels = batch.edges_target.ravel()
-                    classes, counts = np.unique(labels, return_counts=True)
-                    self.strategy.edge_cw = torch.tensor(labels.size / (len(classes) * counts.astype(np.float64)),
-                                                         dtype=torch.float32)
-                self._fast.load_batch(batch.edges_capacity[lo:hi], batch.commodities[lo:hi, :, 2].astype(np.float32),
-                                      batch.nodes[lo:hi], batch.edges_target[lo:hi], self.strategy.edge_cw)
+                if packed:
+                    # the loader already holds this rank's shard as device tensors
+                    if self.strategy.edge_cw is None:
+                        self.strategy.edge_cw = self._class_weights_on_device(batch['y_edges'])
+                    self._fast.load_batch(batch['x_edges_capacity'], batch['x_commodities'], batch['x_nodes'],
+                                          batch['y_edges'], self.strategy.edge_cw)
+                else:
+                    if self.strategy.edge_cw is None:       # global class weights from the first batch of the epoch
+                        labels = batch.edges_target.ravel()
+                        classes, counts = np.unique(labels, return_counts=True)
+                        self.strategy.edge_cw = torch.tensor(labels.size / (len(classes) * counts.astype(np.float64)),
+                                                             dtype=torch.float32)
+                    self._fast.load_batch(batch.edges_capacity[lo:hi], batch.commodities[lo:hi, :, 2].astype(np.float32),
+                                          batch.nodes[lo:hi], batch.edges_target[lo:hi], self.strategy.edge_cw)
                 out = self._fast.step()
                 D.allreduce_mean_(self._fast.flat_grad)
                 self.optimizer.step()
                 loss_val, err_val = (float(v) for v in out[[0, 2]].tolist())   # one sync per step, as the reference's .item()
             else:
-                sub = type(batch)({k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == batch_size else v) for k, v in batch.items()})
-                data = self.strategy.prepare_batch_data(sub, self.device)
+                if packed:
+                    data = batch
+                    if isinstance(self.strategy, SupervisedLearningStrategy) and self.strategy.edge_cw is None:
+                        self.strategy.edge_cw = self._class_weights_on_device(batch['y_edges'])
+                else:
+                    sub = type(batch)({k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == batch_size else v) for k, v in batch.items()})
+                    data = self.strategy.prepare_batch_data(sub, self.device)
                 loss, metrics = self.strategy.compute_loss(self.net, data, self.device)
                 self._sync_grads = True
                 self.strategy.backward_step(loss, self.optimizer, acc, batch_num)
@@ -107,6 +124,32 @@ class Trainer:
             rl_metrics['load_factor'] = rl_metrics.get('avg_finite_load_factor', 0.0)
             rl_metrics['baseline'] = self.strategy.reward_baseline or 0.0
         return time.time() - start, loss, err, rl_metrics
+
+    # ------------------------------------------------------------------ packed dataset
+    def _packed_train_loader(self):
+        """Binary pre-packed training set (written once by rank 0), uploaded in compact form and expanded on the GPU."""
+        from ...common.data_management.packed_dataset import PackedBatchLoader, pack_dataset, pack_file_for
+        if self._packed is None:
+            cfg = self.config
+            path = pack_file_for(cfg, "train")
+            if not path.exists() and D.rank() == 0:
+                pack_dataset(cfg, "train", cfg.get('num_train_data'))
+            if D.world() > 1:
+                torch.distributed.barrier()
+            self._packed = PackedBatchLoader(path, cfg.batch_size, self.device, shuffle=True, seed=cfg.get('seed', 0),
+                                             num_data=cfg.get('num_train_data'), rank=D.rank(), world=D.world())
+        return self._packed
+
+    def _class_weights_on_device(self, y_edges):
+        """n / (2 * count_k) over the whole global batch: label counts of the shards are summed over the ranks."""
+        n1 = y_edges.sum().to(torch.float64)
+        counts = torch.stack([y_edges.numel() - n1, n1])
+        if D.world() > 1:
+            torch.distributed.all_reduce(counts)
+        counts = counts.cpu()
+        k = int((counts > 0).sum())
+        w = torch.where(counts > 0, counts.sum() / (k * counts.clamp(min=1.0)), torch.ones(2, dtype=torch.float64))
+        return w.to(torch.float32)
 
     # ------------------------------------------------------------------ accessors / checkpoints
     def get_model(self):

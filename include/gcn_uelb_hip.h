@@ -212,6 +212,20 @@ int gcn_entropy_grid_bwd(int B, int V, int C, float temperature, const float* y,
                          const float* dout, float* dy, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Expansion of a packed mini-batch into the model's dense input tensors on the GPU, so that only the compact
+ * form is copied from the host.  Replaces the per-sample array construction of DatasetReader.process_batch
+ * (src/common/data_management/dataset_reader.py:117-145: node features from the commodities, edge labels from
+ * the node visiting order) and the per-array conversions and uploads of BaseTrainingStrategy.prepare_batch_data
+ * (src/gcn/training/base_strategy.py:89-102).
+ * Inputs (device): edges_u8 [B,V,V] adjacency, comm_i32 [B,C,3] (src, dst, demand), flow_i16 [B,C,V] visiting
+ * order of each node on the commodity's path (0 = not visited).  Outputs: x_edges int64 [B,V,V], x_nodes int64
+ * [B,V,C], y_edges int64 [B,V,V,C], comm int64 [B,C,3], demand float [B,C].  succ_ws: B*C*V int16 scratch.
+ * ---------------------------------------------------------------------------------------------- */
+int gcn_unpack_batch(int B, int V, int C, const unsigned char* edges_u8, const int* comm_i32, const short* flow_i16,
+                     long long* x_edges, long long* x_nodes, long long* y_edges, long long* comm, float* demand,
+                     short* succ_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adam update of n parameter tensors in one or a few launches (multi-tensor).  Replaces the
  * torch.optim.Adam(lr) step of the trainer (src/gcn/train/trainer.py:95,
  * src/gcn/training/supervised_strategy.py:98-100) with the same arithmetic (no amsgrad; weight_decay is the

@@ -322,13 +322,82 @@ def run_rl_loss_case(name, B, V, C, seed, calls=2, tight=False, **rl):
     np.savez_compressed(path, **out)
     print(f"rl_{name} -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
 
+# ----------------------------------------------------------------------------- dataset-reader cases
+def run_dataset_case(name, graph_model, V, C, N, seed, batch):
+    """Writes a small dataset in the reference's on-disk format with the reference's own graph and commodity
+    generators (node flows: hop-shortest paths instead of ILP solutions, which need a solver that is not
+    installed), then stores what the reference's DatasetReader.process_batch returns for two batches."""
+    import csv
+    import random
+    import shutil
+
+    import importlib.util
+
+    import networkx as nx
+    from src.common.graph.graph_making import Graphs
+    from src.common.graph.graph_utils import generate_commodity
+
+    # the reader module alone: its package's __init__ pulls in the ILP solver bindings (python-mip), which are
+    # not installed here and which reading a dataset does not need
+    spec = importlib.util.spec_from_file_location("ref_dataset_reader", os.path.join("src", "common", "data_management", "dataset_reader.py"))
+    ref_reader = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_reader)
+    DatasetReader = ref_reader.DatasetReader
+
+    random.seed(seed)
+    np.random.seed(seed)
+    root = os.path.join(OUT, "datasets")
+    mode_dir = os.path.join(root, name, "train_data")
+    shutil.rmtree(os.path.join(root, name), ignore_errors=True)
+    for i in range(N):
+        bucket = i - i % 10
+        for d in ("graph_file", "commodity_file", "node_flow_file"):
+            os.makedirs(os.path.join(mode_dir, d, str(bucket)), exist_ok=True)
+        G = Graphs(C)
+        if graph_model == "nsfnet":
+            G.nsfnet(G, 1000, 5000)
+        else:
+            G.randomGraph(G, 3, V, 1000, 10000)
+        comm = generate_commodity(G, 5, 500, C)
+        nx.write_gml(G, os.path.join(mode_dir, "graph_file", str(bucket), f"graph_{i}.gml"))
+        with open(os.path.join(mode_dir, "commodity_file", str(bucket), f"commodity_data_{i}.csv"), "w", newline="") as f:
+            csv.writer(f).writerows(comm)
+        nodes = list(G.nodes)
+        flow = []
+        for s, t, _ in comm:
+            p = nx.shortest_path(G, s, t)
+            row = [0] * len(nodes)
+            for k, n in enumerate(p):
+                row[nodes.index(n)] = k + 1
+            flow.append(row)
+        with open(os.path.join(mode_dir, "node_flow_file", str(bucket), f"node_flow_{i}.csv"), "w", newline="") as f:
+            csv.writer(f).writerows(flow)
+        with open(os.path.join(mode_dir, "exact_solution.csv"), "a", newline="") as f:
+            csv.writer(f).writerow([round(random.uniform(0.2, 0.95), 6), round(random.uniform(0.01, 2.0), 4), None])
+    cfg = dict(data_root=root, dataset_name=name)
+    env = os.environ.pop("GCN_UELB_DATA_ROOT", None)
+    try:
+        reader = DatasetReader(N, batch, "train", cfg, shuffle=False)
+        out = dict(cfg_N=N, cfg_V=V, cfg_C=C, cfg_batch=batch)
+        for k, idx in enumerate([np.arange(batch), np.arange(N - batch, N)[::-1].copy()]):
+            b = reader.process_batch(idx)
+            out[f"b{k}.indices"] = idx
+            for key in ("edges", "edges_capacity", "edges_target", "nodes", "nodes_target", "commodities", "load_factor"):
+                out[f"b{k}.{key}"] = np.asarray(b[key])
+    finally:
+        if env is not None:
+            os.environ["GCN_UELB_DATA_ROOT"] = env
+    path = os.path.join(OUT, f"dataset_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"dataset_{name}: {N} samples -> {mode_dir}; reader output -> {path} ({os.path.getsize(path) / 1e3:.1f} kB)")
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--only", default="", help="comma-separated groups to regenerate: model, beam, sampler, rl (default all)")
+    ap.add_argument("--only", default="", help="comma-separated groups to regenerate: model, beam, sampler, rl, dataset (default all)")
     args = ap.parse_args()
-    groups = set(args.only.split(",")) if args.only else {"model", "beam", "sampler", "rl"}
+    groups = set(args.only.split(",")) if args.only else {"model", "beam", "sampler", "rl", "dataset"}
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
     os.chdir(args.ref)
@@ -348,6 +417,9 @@ def main():
                          rl_baseline_momentum=0.95)
         run_rl_loss_case("tight", 5, 8, 6, seed=42, calls=3, tight=True, rl_sampling_top_p=0.9, rl_entropy_weight=0.01,
                          rl_entropy_epsilon=0.0, rl_normalize_advantages=False)
+    if "dataset" in groups:
+        run_dataset_case("nsf_small", "nsfnet", 14, 4, 12, seed=51, batch=5)
+        run_dataset_case("rand_small", "random", 9, 3, 6, seed=52, batch=3)
     if "model" in groups:
         run_model_cases()
     if "beam" in groups:

@@ -1,0 +1,149 @@
+graph [
+  directed 1
+  node [
+    id 0
+    label "0"
+  ]
+  node [
+    id 1
+    label "1"
+  ]
+  node [
+    id 2
+    label "2"
+  ]
+  node [
+    id 3
+    label "3"
+  ]
+  node [
+    id 4
+    label "4"
+  ]
+  node [
+    id 5
+    label "5"
+  ]
+  node [
+    id 6
+    label "6"
+  ]
+  node [
+    id 7
+    label "7"
+  ]
+  node [
+    id 8
+    label "8"
+  ]
+  edge [
+    source 0
+    target 1
+    capacity 4121
+  ]
+  edge [
+    source 0
+    target 8
+    capacity 5342
+  ]
+  edge [
+    source 0
+    target 3
+    capacity 9684
+  ]
+  edge [
+    source 1
+    target 0
+    capacity 4121
+  ]
+  edge [
+    source 1
+    target 2
+    capacity 5772
+  ]
+  edge [
+    source 1
+    target 5
+    capacity 9525
+  ]
+  edge [
+    source 2
+    target 1
+    capacity 5772
+  ]
+  edge [
+    source 2
+    target 3
+    capacity 5419
+  ]
+  edge [
+    source 3
+    target 0
+    capacity 9684
+  ]
+  edge [
+    source 3
+    target 2
+    capacity 5419
+  ]
+  edge [
+    source 3
+    target 4
+    capacity 8022
+  ]
+  edge [
+    source 4
+    target 3
+    capacity 8022
+  ]
+  edge [
+    source 4
+    target 5
+    capacity 2324
+  ]
+  edge [
+    source 5
+    target 1
+    capacity 9525
+  ]
+  edge [
+    source 5
+    target 4
+    capacity 2324
+  ]
+  edge [
+    source 5
+    target 6
+    capacity 8462
+  ]
+  edge [
+    source 6
+    target 5
+    capacity 8462
+  ]
+  edge [
+    source 6
+    target 7
+    capacity 3050
+  ]
+  edge [
+    source 7
+    target 6
+    capacity 3050
+  ]
+  edge [
+    source 7
+    target 8
+    capacity 1406
+  ]
+  edge [
+    source 8
+    target 0
+    capacity 5342
+  ]
+  edge [
+    source 8
+    target 7
+    capacity 1406
+  ]
+]
