@@ -128,6 +128,51 @@ def beam_bench(shape, batch, device, K=10):
             "paths_bit_exact_vs_oracle": same}
 
 
+def sampler_bench(shape, batch, device):
+    """REINFORCE path sampling (temperature 1.5, top-p 0.95, eps 0.05: the reference's rl_finetuning config) on
+    random edge scores of the benchmark shape: GPU sample + log-probability backward per batch vs the CPU
+    restatement on a few graphs; the CPU paths must equal the GPU's for the same counter-based draws."""
+    from oracle import sampler_oracle
+    from src.gcn.algorithms.path_sampler import PathSampler
+    B, V, C = shape["B"], shape["V"], shape["C"]
+    g = torch.Generator().manual_seed(11)
+    y = (torch.randn((B, V, V, C), generator=g) * 2.0)
+    y[torch.from_numpy(batch["edges_capacity"] == 0).unsqueeze(-1).expand_as(y)] = -1e9
+    yd = y.to(device).requires_grad_(True)
+    cap = torch.from_numpy(batch["edges_capacity"]).to(device)
+    comm = torch.from_numpy(batch["commodities"]).to(device)
+    s = PathSampler(yd, cap, comm, temperature=1.5, top_p=0.95, entropy_epsilon=0.05)
+    w = torch.ones(B, device=device)
+
+    def one():
+        yd.grad = None
+        out = s._run()
+        out[0].backward(w)
+        return out
+
+    one()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.time()
+    for _ in range(reps):
+        out = one()
+    torch.cuda.synchronize()
+    gpu_s = (time.time() - t0) / reps
+    seed, call = s.last_rng
+    nb = min(B, 4)
+    t0 = time.time()
+    op, *_ = sampler_oracle.sample(y[:nb], batch["edges_capacity"][:nb], batch["commodities"][:nb], 1.5, 0.95, 0.05,
+                                   uniform=sampler_oracle.counter_uniform(seed, call))
+    cpu_s = (time.time() - t0) / nb
+    paths, plen = out[1].cpu().numpy(), out[2].cpu().numpy()
+    got = [[[int(v) for v in paths[b, c, :plen[b, c]]] for c in range(C)] for b in range(nb)]
+    same = sum(got[b][c] == op[b][c] for b in range(nb) for c in range(C))
+    return {"temperature": 1.5, "top_p": 0.95, "eps": 0.05, "graphs_per_s": round(B / gpu_s, 1),
+            "ms_per_batch": round(gpu_s * 1e3, 3), "includes": "sampling, log-probabilities and their backward",
+            "cpu_oracle_graphs_per_s": round(1.0 / cpu_s, 2), "cpu_cores": 1,
+            "paths_equal_to_oracle": f"{same}/{nb * C}"}
+
+
 def _stage(msg):
     """Progress line on stderr (GCN_BENCH_VERBOSE=1): which rank reached which stage."""
     if os.environ.get("GCN_BENCH_VERBOSE"):
@@ -294,6 +339,11 @@ def main():
                 out["beam_search"] = beam_bench(shape, batch, device)
             except Exception as ex:      # the headline metric must still be reported
                 out["beam_search"] = {"error": repr(ex)}
+            if shape["V"] <= 256:
+                try:
+                    out["path_sampler"] = sampler_bench(shape, batch, device)
+                except Exception as ex:
+                    out["path_sampler"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
