@@ -184,12 +184,21 @@ LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     return w;
 }
 
+// workgroups of one slab reduction, and the grid x of a launch that runs several
+int red_blocks(const ReduceJob& j) { const int c = reduce_cols(j.nP); return (j.ncols + c - 1) / c; }
+int red_grid(const ReduceJobs& jobs) {
+    int g = 1;
+    for (int k = 0; k < jobs.n; ++k) g = std::max(g, red_blocks(jobs.job[k]));
+    return g;
+}
+
 int tn_slices(size_t rows) {
     const size_t ntiles = (rows + 15) / 16;
     return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
 }
 
 constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
+constexpr int kFinGroup = 16;          // workgroups per group of the in-kernel finish of BatchNorm-backward sums
 
 struct LayerBwdWs {
     float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
@@ -333,6 +342,52 @@ void bn_finish_job(ReduceJob& j, const float* partial, int nP, int H, double n, 
     j.rd.off[0] = 0; j.rd.off[1] = H; j.rd.off[2] = 2 * H;
 }
 
+// edge kernel of a layer's backward data path
+template <int MT>
+int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
+                    const float* const* P, const float* const* wT, const LayerSaved& S, float* dx, float* de,
+                    const LayerBwdWs& W, int& npart_e, const NextLayer& nx, hipStream_t st) {
+    const int H = d.H;
+    EdgeBwdArgs a = {};
+    a.B = d.B; a.V = d.V; a.C = d.C; a.H = H; a.IT = d.IT; a.mean_agg = agg;
+    a.de = de; a.e_tmp = S.e_tmp; a.WUt = wT[2];
+    a.Vn = S.Vn; a.Aagg = S.A; a.Dn = S.D; a.dx = dx; a.x_tmp = S.x_tmp; a.stats = S.stats;
+    a.gamma_e = P[10]; a.beta_e = P[11]; a.gamma_x = P[8]; a.beta_x = P[9];
+    a.bstats_e = W.bstats_e; a.bstats_x = W.bstats_x;
+    a.det_out = W.det; a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn;
+    a.rng = rng; a.sid_e = 2 * sid; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
+    if (nx.on) {
+        a.next.tmp = nx.e_tmp; a.next.mean = nx.stats; a.next.rstd = nx.stats + H; a.next.gamma = nx.gamma_e;
+        a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
+    }
+    const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
+    int blocks = range_blocks(units, kEdgeGrid);
+    if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
+    if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
+    else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
+    if (nx.on) npart_e = blocks;
+    return 0;
+}
+
+// arguments of the node kernel of a layer's backward data path; dx_tmp / dVn / dVe go to the given buffers
+NodeBwdArgs node_bwd_args(const Dims& d, float p, int training, const unsigned long long* rng, int sid, const float* const* P,
+                          const float* const* wT, const LayerSaved& S, float* dx, const LayerBwdWs& W, float* dxtmp, float* dVn,
+                          float* dVe, const NextLayer& nx) {
+    const int H = d.H;
+    NodeBwdArgs a = {};
+    a.rows = (int)d.Rn; a.H = H; a.njt = d.njt; a.nit = d.nit;
+    a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn; a.dx = dx; a.x_tmp = S.x_tmp;
+    a.mean = S.stats + 2 * H; a.rstd = S.stats + 3 * H; a.gamma = P[8]; a.beta = P[9]; a.bstats = W.bstats_x;
+    a.WnUt = wT[0]; a.WnVt = wT[1]; a.WeVt = wT[3];
+    a.dxtmp_out = dxtmp; a.dVe_out = dVe; a.dVn_out = dVn;
+    a.rng = rng; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
+    if (nx.on) {
+        a.next.tmp = nx.x_tmp; a.next.mean = nx.stats + 2 * H; a.next.rstd = nx.stats + 3 * H; a.next.gamma = nx.gamma_x;
+        a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
+    }
+    return a;
+}
+
 // Backward of one layer, data path: edge kernel, node kernel.  bstats_e / bstats_x and this layer's BatchNorm
 // gradients must be finished (with fin_first they are reduced here from npart_e / npart_x partial rows).  On
 // return, if nx.on, bpart_e / bpart_x hold npart_e / npart_x partial rows of the layer below.
@@ -349,42 +404,13 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
         bn_finish_job(jobs.job[0], W.bpart_e, npart_e, H, (double)d.Re, G[11], G[10], W.bstats_e);
         bn_finish_job(jobs.job[1], W.bpart_x, npart_x, H, (double)d.Rn, G[9], G[8], W.bstats_x);
         GCN_PROF_PRE("k_reduce_slabs(bn)");
-        k_reduce_slabs<<<dim3((2 * H + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+        k_reduce_slabs<<<dim3(red_grid(jobs), 2, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(bn)");
     }
+    if (int rc = launch_edge_bwd<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, W, npart_e, nx, st)) return rc;
     {
-        EdgeBwdArgs a = {};
-        a.B = d.B; a.V = d.V; a.C = d.C; a.H = H; a.IT = d.IT; a.mean_agg = agg;
-        a.de = de; a.e_tmp = S.e_tmp; a.WUt = wT[2];
-        a.Vn = S.Vn; a.Aagg = S.A; a.Dn = S.D; a.dx = dx; a.x_tmp = S.x_tmp; a.stats = S.stats;
-        a.gamma_e = P[10]; a.beta_e = P[11]; a.gamma_x = P[8]; a.beta_x = P[9];
-        a.bstats_e = W.bstats_e; a.bstats_x = W.bstats_x;
-        a.det_out = W.det; a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn;
-        a.rng = rng; a.sid_e = 2 * sid; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
-        if (nx.on) {
-            a.next.tmp = nx.e_tmp; a.next.mean = nx.stats; a.next.rstd = nx.stats + H; a.next.gamma = nx.gamma_e;
-            a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
-        }
-        const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-        int blocks = range_blocks(units, kEdgeGrid);
-        if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
-        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
-        else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
-        if (nx.on) npart_e = blocks;
-    }
-    {
-        NodeBwdArgs a = {};
-        a.rows = (int)d.Rn; a.H = H; a.njt = d.njt; a.nit = d.nit;
-        a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn; a.dx = dx; a.x_tmp = S.x_tmp;
-        a.mean = S.stats + 2 * H; a.rstd = S.stats + 3 * H; a.gamma = P[8]; a.beta = P[9]; a.bstats = W.bstats_x;
-        a.WnUt = wT[0]; a.WnVt = wT[1]; a.WeVt = wT[3];
-        a.dxtmp_out = W.dxtmp; a.dVe_out = W.dVe; a.dVn_out = W.dVn;
-        a.rng = rng; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
-        if (nx.on) {
-            a.next.tmp = nx.x_tmp; a.next.mean = nx.stats + 2 * H; a.next.rstd = nx.stats + 3 * H; a.next.gamma = nx.gamma_x;
-            a.next.beta = nx.beta_x; a.next.drop_sid = 2 * nx.sid + 1; a.next.partial = W.bpart_x;
-        }
         const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+        const NodeBwdArgs a = node_bwd_args(d, p, training, rng, sid, P, wT, S, dx, W, W.dxtmp, W.dVn, W.dVe, nx);
         if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_bwd_w", k_node_bwd_w, blocks, 256, a);
         else GCN_LAUNCH_TIMED("k_node_bwd3", (k_node_bwd3<MT>), blocks, 64 * MT, a);
         if (nx.on) npart_x = blocks;
@@ -476,7 +502,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     jobs.n = 2;
     layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W, W.tn_e, W.tn_n, G);
     GCN_PROF_PRE("k_reduce_slabs(layer)");
-    k_reduce_slabs<<<dim3((3 * (H * H + H) + 15) / 16, 2, 1), GCN_BLOCK, 0, st>>>(jobs);
+    k_reduce_slabs<<<dim3(red_grid(jobs), 2, 1), GCN_BLOCK, 0, st>>>(jobs);
     GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
     return 0;
 }
@@ -543,6 +569,9 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
 struct ModelBwdWs {
     LayerBwdWs lw;
     float *tn_e2, *tn_n2;           // second set of product slabs: layer l's products are written while layer l+1's are reduced
+    float *nd2[3];                  // second set of dx_tmp / dVn / dVe: layer l's node backward writes while layer l+1's products read
+    int* fin_counters;              // arrival counters of the in-kernel BatchNorm-backward finish (zero between launches)
+    double* fin_gsum;
     float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
     int* emb_cnt;
     int head_blk, S_h, emb_blk;
@@ -555,6 +584,10 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
         const size_t slab = (size_t)p.d.H * p.d.H + p.d.H;
         w.tn_e2 = b.f((size_t)w.lw.S_e * slab);
         w.tn_n2 = b.f((size_t)w.lw.S_n * 3 * slab);
+        for (int k = 0; k < 3; ++k) w.nd2[k] = b.f(p.d.Rn * p.d.H);
+        const size_t ng = (kMaxPartBlocks + kFinGroup - 1) / kFinGroup;
+        w.fin_counters = (int*)b.raw((ng + 1) * sizeof(int));
+        w.fin_gsum = (double*)b.raw(ng * 2 * p.d.H * sizeof(double));
     }
     w.de = b.f(eh);
     w.dx = b.f(p.d.Rn * p.d.H);
@@ -860,6 +893,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     ZeroJobs hz = {};
     hz.p[0] = W.dx; hz.n[0] = nh;
     hz.p[1] = W.lw.bpart_x; hz.n[1] = 2 * (size_t)H;
+    hz.p[2] = reinterpret_cast<float*>(W.fin_counters); hz.n[2] = (kMaxPartBlocks + kFinGroup - 1) / kFinGroup + 1;
     GCN_PROF_PRE("k_head_bwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
                                                                       dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
@@ -901,7 +935,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             WgradMap map = {};
             int nb = 0;
             for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += k < p.NHID ? hpr.nslices[k] : 0; }
-            for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < jobs.n) nb += (jobs.job[k].ncols + 15) / 16; }
+            for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < jobs.n) nb += red_blocks(jobs.job[k]); }
             map.seg[8] = nb;
             DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad(head)", (k_wgrad<MT>), nb, GCN_BLOCK, H, hpr, jobs, map));
             head_tn_pending = p.NHID > 0;
@@ -910,67 +944,140 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                 if (int rc = launch_tn<0>(H, hpr, p.NHID, W.S_h, st)) return rc;
                 jobs.job[jobs.n++] = head_tn_job;
             }
-            int maxcols = 0;
-            for (int k = 0; k < jobs.n; ++k) maxcols = std::max(maxcols, jobs.job[k].ncols);
             GCN_PROF_PRE("k_reduce_slabs(head)");
-            k_reduce_slabs<<<dim3((maxcols + 15) / 16, jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
+            k_reduce_slabs<<<dim3(red_grid(jobs), jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
             GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
         }
     }
-    for (int l = p.L - 1; l >= 0; --l) {
-        const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
-        const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
-        float* const* LG = G + 3 + GCN_LAYER_NPARAMS * l;
-        const float* wT[4];
-        for (int k = 0; k < 4; ++k) wT[k] = W.wT + (size_t)(4 * l + k) * hh2;
-        NextLayer nx = {};
-        if (l > 0) {
-            const PrevLayer below = prev_of(p, saved, P, l - 1);
-            nx.on = true; nx.e_tmp = below.e_tmp; nx.x_tmp = below.x_tmp; nx.stats = below.stats;
-            nx.gamma_x = below.gamma_x; nx.beta_x = below.beta_x; nx.gamma_e = below.gamma_e; nx.beta_e = below.beta_e; nx.sid = l - 1;
-            nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
-        }
-        int rc = 0;
-        DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de, LG, W.lw,
-                                                  npart_e, npart_x, nx, false, st));
-        if (rc) return rc;
-        // one launch: this layer's weight-gradient products, the reduction of the layer above's products and the
-        // BatchNorm-backward finish of the layer below (its partial sums were just written)
-        float* tn_e = (l & 1) ? W.tn_e2 : W.lw.tn_e;
-        float* tn_n = (l & 1) ? W.tn_n2 : W.lw.tn_n;
-        TnProblems pr = {};
-        layer_tn_problems(pr, d, W.lw, x_act + (size_t)l * nh, e_act + (size_t)l * eh, tn_e, tn_n);
-        ReduceJobs jobs = {};
-        WgradMap map = {};
-        int nb = 0;
-        for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += pr.nslices[k]; }
-        int nj = 0;
-        if (l + 1 < p.L) {
-            float* const* UG = G + 3 + GCN_LAYER_NPARAMS * (l + 1);
-            layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, (l & 1) ? W.lw.tn_e : W.tn_e2, (l & 1) ? W.lw.tn_n : W.tn_n2, UG);
-            nj = 2;
-        }
-        if (nx.on) {
-            bn_finish_job(jobs.job[nj], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
-            bn_finish_job(jobs.job[nj + 1], W.lw.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.lw.bstats_x);
-            nj += 2;
-        }
-        if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // only in the top layer's launch: nj <= 3
-        jobs.n = nj;
-        for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += (jobs.job[k].ncols + 15) / 16; }
-        map.seg[8] = nb;
-        if (d.MT > 4) {
-            // wide path: the products and the ready reduce jobs as two launches
-            if (int rc2 = launch_tn<0>(H, pr, 4, std::max(W.lw.S_e, W.lw.S_n), st)) return rc2;
-            if (nj > 0) {
-                int maxcols = 0;
-                for (int k = 0; k < nj; ++k) maxcols = std::max(maxcols, jobs.job[k].ncols);
-                GCN_PROF_PRE("k_reduce_slabs(layer)");
-                k_reduce_slabs<<<dim3((maxcols + 15) / 16, nj, 1), GCN_BLOCK, 0, st>>>(jobs);
-                GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
+    if (d.MT > 4) {
+        for (int l = p.L - 1; l >= 0; --l) {
+            const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
+            const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
+            float* const* LG = G + 3 + GCN_LAYER_NPARAMS * l;
+            const float* wT[4];
+            for (int k = 0; k < 4; ++k) wT[k] = W.wT + (size_t)(4 * l + k) * hh2;
+            NextLayer nx = {};
+            if (l > 0) {
+                const PrevLayer below = prev_of(p, saved, P, l - 1);
+                nx.on = true; nx.e_tmp = below.e_tmp; nx.x_tmp = below.x_tmp; nx.stats = below.stats;
+                nx.gamma_x = below.gamma_x; nx.beta_x = below.beta_x; nx.gamma_e = below.gamma_e; nx.beta_e = below.beta_e; nx.sid = l - 1;
+                nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
             }
-        } else {
-            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
+            int rc = 0;
+            DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de, LG, W.lw,
+                                                      npart_e, npart_x, nx, false, st));
+            if (rc) return rc;
+            // one launch: this layer's weight-gradient products, the reduction of the layer above's products and the
+            // BatchNorm-backward finish of the layer below (its partial sums were just written)
+            float* tn_e = (l & 1) ? W.tn_e2 : W.lw.tn_e;
+            float* tn_n = (l & 1) ? W.tn_n2 : W.lw.tn_n;
+            TnProblems pr = {};
+            layer_tn_problems(pr, d, W.lw, x_act + (size_t)l * nh, e_act + (size_t)l * eh, tn_e, tn_n);
+            ReduceJobs jobs = {};
+            WgradMap map = {};
+            int nb = 0;
+            for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += pr.nslices[k]; }
+            int nj = 0;
+            if (l + 1 < p.L) {
+                float* const* UG = G + 3 + GCN_LAYER_NPARAMS * (l + 1);
+                layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, (l & 1) ? W.lw.tn_e : W.tn_e2, (l & 1) ? W.lw.tn_n : W.tn_n2, UG);
+                nj = 2;
+            }
+            if (nx.on) {
+                bn_finish_job(jobs.job[nj], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
+                bn_finish_job(jobs.job[nj + 1], W.lw.bpart_x, npart_x, H, (double)d.Rn, nx.G[9], nx.G[8], W.lw.bstats_x);
+                nj += 2;
+            }
+            if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // only in the top layer's launch: nj <= 3
+            jobs.n = nj;
+            for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += red_blocks(jobs.job[k]); }
+            map.seg[8] = nb;
+            if (d.MT > 4) {
+                // wide path: the products and the ready reduce jobs as two launches
+                if (int rc2 = launch_tn<0>(H, pr, 4, std::max(W.lw.S_e, W.lw.S_n), st)) return rc2;
+                if (nj > 0) {
+                    GCN_PROF_PRE("k_reduce_slabs(layer)");
+                    k_reduce_slabs<<<dim3(red_grid(jobs), nj, 1), GCN_BLOCK, 0, st>>>(jobs);
+                    GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
+                }
+            } else {
+                DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
+            }
+        }
+    } else {
+        // H <= 64: two launches per layer.  After the edge kernel of layer l, one launch runs the node kernel of layer l
+        // (which also finishes the BatchNorm backward of layer l-1's node BatchNorm) next to the products and
+        // reductions that are ready: the edge product of layer l, the node products of layer l+1 (their operands
+        // come from layer l+1's node kernel, hence the second set of node buffers), the slabs written by the
+        // launch before, and the BatchNorm-backward sums the edge kernel just produced.
+        auto ndbuf = [&](int l, int k) { return (l & 1) ? W.nd2[k] : (k == 0 ? W.lw.dxtmp : k == 1 ? W.lw.dVn : W.lw.dVe); };
+        auto tn_e_of = [&](int l) { return (l & 1) ? W.tn_e2 : W.lw.tn_e; };
+        auto tn_n_of = [&](int l) { return (l & 1) ? W.tn_n2 : W.lw.tn_n; };
+        auto node_problems = [&](TnProblems& pr, int slot0, int l) {       // node_feat.U, node_feat.V, edge_feat.V of layer l
+            for (int k = 0; k < 3; ++k) {
+                pr.X[slot0 + k] = ndbuf(l, k); pr.Y[slot0 + k] = x_act + (size_t)l * nh;
+                pr.rows[slot0 + k] = d.Rn; pr.nslices[slot0 + k] = W.lw.S_n;
+                pr.out[slot0 + k] = tn_n_of(l) + (size_t)k * slab; pr.out_stride[slot0 + k] = 3 * slab;
+            }
+        };
+        for (int l = p.L - 1; l >= 0; --l) {
+            const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
+            const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
+            const float* wT[4];
+            for (int k = 0; k < 4; ++k) wT[k] = W.wT + (size_t)(4 * l + k) * hh2;
+            NextLayer nx = {};
+            if (l > 0) {
+                const PrevLayer below = prev_of(p, saved, P, l - 1);
+                nx.on = true; nx.e_tmp = below.e_tmp; nx.x_tmp = below.x_tmp; nx.stats = below.stats;
+                nx.gamma_x = below.gamma_x; nx.beta_x = below.beta_x; nx.gamma_e = below.gamma_e; nx.beta_e = below.beta_e; nx.sid = l - 1;
+                nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
+            }
+            int rc = 0;
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) rc = launch_edge_bwd<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S,
+                                                                              W.dx, W.de, W.lw, npart_e, nx, st));
+            if (rc) return rc;
+            NodeBwdArgs na = node_bwd_args(d, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.lw, ndbuf(l, 0), ndbuf(l, 1),
+                                           ndbuf(l, 2), nx);
+            static const bool nofin = getenv("GCN_TUNE_NOFIN") != nullptr;      // timing probe: results are then wrong
+            if (nx.on && !nofin) {
+                na.fin.counters = W.fin_counters; na.fin.gsum = W.fin_gsum; na.fin.group = kFinGroup;
+                na.fin.dbeta = nx.G[9]; na.fin.dgamma = nx.G[8]; na.fin.bstats = W.lw.bstats_x; na.fin.inv_n = 1.0 / (double)d.Rn;
+            }
+            TnProblems pr = {};
+            pr.X[0] = W.lw.det; pr.Y[0] = e_act + (size_t)l * eh; pr.rows[0] = d.Re; pr.nslices[0] = W.lw.S_e;
+            pr.out[0] = tn_e_of(l); pr.out_stride[0] = slab;
+            if (l + 1 < p.L) node_problems(pr, 1, l + 1);
+            ReduceJobs jobs = {};
+            ReduceJob unused = {};
+            int nj = 0;
+            if (l + 1 < p.L) layer_wgrad_jobs(jobs.job[nj++], unused, d, W.lw, tn_e_of(l + 1), tn_n_of(l + 1), G + 3 + GCN_LAYER_NPARAMS * (l + 1));
+            if (l + 2 < p.L) layer_wgrad_jobs(unused, jobs.job[nj++], d, W.lw, tn_e_of(l + 2), tn_n_of(l + 2), G + 3 + GCN_LAYER_NPARAMS * (l + 2));
+            if (nx.on) bn_finish_job(jobs.job[nj++], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
+            if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // top layer only: nj <= 2 there
+            jobs.n = nj;
+            MidMap map = {};
+            int nb = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+            map.seg[1] = nb;
+            for (int k = 0; k < 4; ++k) { nb += pr.nslices[k]; map.seg[2 + k] = nb; }
+            for (int k = 0; k < 4; ++k) { if (k < nj) nb += red_blocks(jobs.job[k]); map.seg[6 + k] = nb; }
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_bwd_mid", (k_bwd_mid<MT>), nb, GCN_BLOCK, na, H, pr, jobs, map));
+        }
+        // what is left after layer 0: its node products, and the slabs of the last launch
+        {
+            TnProblems pr = {};
+            node_problems(pr, 0, 0);
+            ReduceJobs jobs = {};
+            ReduceJob unused = {};
+            int nj = 0;
+            layer_wgrad_jobs(jobs.job[nj++], unused, d, W.lw, tn_e_of(0), tn_n_of(0), G + 3);
+            if (p.L > 1) layer_wgrad_jobs(unused, jobs.job[nj++], d, W.lw, tn_e_of(1), tn_n_of(1), G + 3 + GCN_LAYER_NPARAMS);
+            jobs.n = nj;
+            WgradMap map = {};
+            int nb = 0;
+            for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += pr.nslices[k]; }
+            for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += red_blocks(jobs.job[k]); }
+            map.seg[8] = nb;
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad(tail)", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
         }
     }
     // embeddings
@@ -984,12 +1091,16 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     {
         // one reduce launch: products of layer 0 (slab set 0) and the edge-embedding gradient
         ReduceJobs jobs = {};
-        jobs.n = 3;
-        layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);
-        jobs.job[2].partial = W.embpart; jobs.job[2].nP = d.MT > 4 ? W.emb_blk : W.emb_blk * GCN_WAVES_PER_BLOCK; jobs.job[2].ncols = H;
-        jobs.job[2].rd.n = 1; jobs.job[2].rd.dst[0] = G[2]; jobs.job[2].rd.off[0] = 0; jobs.job[2].rd.off[1] = H;
+        ReduceJob unused = {};
+        int nj = 0;
+        if (d.MT > 4) { layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3); nj = 2; }
+        else layer_wgrad_jobs(unused, jobs.job[nj++], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);       // node products of layer 0
+        ReduceJob& je = jobs.job[nj++];
+        je.partial = W.embpart; je.nP = d.MT > 4 ? W.emb_blk : W.emb_blk * GCN_WAVES_PER_BLOCK; je.ncols = H;
+        je.rd.n = 1; je.rd.dst[0] = G[2]; je.rd.off[0] = 0; je.rd.off[1] = H;
+        jobs.n = nj;
         GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");
-        k_reduce_slabs<<<dim3((3 * slab + 15) / 16, 3, 1), GCN_BLOCK, 0, st>>>(jobs);
+        k_reduce_slabs<<<dim3(red_grid(jobs), nj, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0, edge embedding)");
     }
     {

@@ -139,12 +139,12 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 
 // Buffers a kernel clears on the side for later kernels of the same stream (saves separate fill launches).
 struct ZeroJobs {
-    float* p[2];
-    size_t n[2];      // 32-bit words
+    float* p[3];
+    size_t n[3];      // 32-bit words
 };
 __device__ __forceinline__ void zero_fill(const ZeroJobs& z) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n[k]; i += (size_t)gridDim.x * blockDim.x) z.p[k][i] = 0.f;
 }
 

@@ -115,28 +115,32 @@ struct ReduceJobs {
     ReduceJob job[4];
     int n;
 };
-// Sum of the nP partial rows of 16 columns (colblock) of one job, in a fixed order, accumulated in fp64.
+// Columns per workgroup of a slab reduction: few partial rows -> wide column blocks (fewer, fuller workgroups),
+// many rows -> narrow blocks with more threads along the rows.  Host and device use the same rule.
+__host__ __device__ inline int reduce_cols(int nP) { return nP <= 64 ? 64 : (nP <= 256 ? 32 : 16); }
+// Sum of the nP partial rows of one column block of one job, in a fixed order, accumulated in fp64.
 // Needs all 256 threads of the workgroup.
-__device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int colblock, double* lds /* [64 * 16] */) {
+__device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int colblock, double* lds /* [256 * 4] */) {
     const float* __restrict__ partial = J.partial;
     const int nP = J.nP, ncols = J.ncols;
-    const int cg = threadIdx.x & 3, pg = threadIdx.x >> 2;
-    const int col = colblock * 16 + cg * 4;
-    if (colblock * 16 >= ncols) return;          // uniform per workgroup
+    const int bcols = reduce_cols(nP), ncg = bcols >> 2, npg = 256 / ncg;     // column groups of 4, row groups
+    const int cg = threadIdx.x % ncg, pg = threadIdx.x / ncg;
+    const int col = colblock * bcols + cg * 4;
+    if (colblock * bcols >= ncols) return;          // uniform per workgroup
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (col < ncols) {
-        for (int p = pg; p < nP; p += 64) {
+        for (int p = pg; p < nP; p += npg) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)p * ncols + col);
             a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
         }
     }
-    double* my = lds + pg * 16 + cg * 4;
+    double* my = lds + pg * bcols + cg * 4;
     my[0] = a0; my[1] = a1; my[2] = a2; my[3] = a3;
     __syncthreads();
-    for (int sft = 32; sft > 0; sft >>= 1) {
+    for (int sft = npg >> 1; sft > 0; sft >>= 1) {
         if (pg < sft) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) my[k] += my[sft * 16 + k];
+            for (int k = 0; k < 4; ++k) my[k] += my[sft * bcols + k];
         }
         __syncthreads();
     }
@@ -153,7 +157,7 @@ __device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int colbloc
         }
     }
 }
-// grid = (ceil(max ncols / 16), number of jobs)
+// grid = (largest number of column blocks of a job, number of jobs)
 __global__ __launch_bounds__(GCN_BLOCK) void k_reduce_slabs(ReduceJobs jobs) {
     __shared__ double lds[64 * 16];
     reduce_slab_body(jobs.job[blockIdx.y], blockIdx.x, lds);

@@ -208,6 +208,19 @@ struct EdgeBwdArgs {
 // dx_tmp, dVe, dVn are written out for the weight-gradient GEMMs; optionally the BatchNorm-backward
 // statistics of layer l-1's node BatchNorm are accumulated from dx_in.
 // ------------------------------------------------------------------------------------------------
+// Finish of a cross-workgroup column sum inside the kernel that produced the partial rows: workgroups are
+// grouped by index; the last workgroup of a group to arrive (device-scope counter) adds the group's rows in index
+// order, and the last group to finish adds the group sums in index order and writes the result.  Which workgroup
+// does the adding depends on timing, what it adds and in which order does not: results are bit-reproducible.
+// counters: ngroups + 1 ints, zero before the launch and zero again after it; gsum: ngroups * ncols doubles.
+struct LastBlockFinish {
+    int* counters;
+    double* gsum;
+    int group;                 // workgroups per group
+    float* dbeta; float* dgamma; float* bstats;      // BatchNorm-backward results of the layer below
+    double inv_n;
+};
+
 struct NodeBwdArgs {
     int rows, H, njt, nit;
     const float* rowpart; const float* colVe; const float* colVn;
@@ -217,5 +230,6 @@ struct NodeBwdArgs {
     float* dxtmp_out; float* dVe_out; float* dVn_out;
     const unsigned long long* rng; int sid_x; float p; int training;
     NextBn next;
+    LastBlockFinish fin;       // counters != nullptr: the sums of next.partial are finished by this kernel
 };
 

@@ -508,14 +508,90 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // Node backward of layer l (math: see NodeBwdArgs): one workgroup per 16-row tile.
 // ------------------------------------------------------------------------------------------------
+// Device-coherent store of four floats (one 32-bit store each, performed at device scope): for the few values
+// that another workgroup of the same launch reads.  A device-scope release fence would do for ordinary stores too,
+// but it writes back the whole L2 of the XCD, which costs far more than the kernel around it.
+__device__ __forceinline__ void st4_dev(float* p, const f32x4& v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(p + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by every thread of every workgroup after workgroup bid of nb has stored its row of `partial` ([nb][ncols], ncols <=
+// the number of calling threads) has been stored with st4_dev.  Returns true in the one workgroup that holds the totals:
+// tot[0 .. ncols) in LDS (ncols doubles, scratch also used for the hand-over of the arrival tickets).
+// Ordering: every value handed between workgroups is stored and loaded at device scope; a workgroup-scope release
+// fence (wait for the stores to be acknowledged) plus the barrier orders them before the arrival counter's
+// device-scope increment, and the reader takes its ticket before it loads.
+__device__ __forceinline__ bool last_block_totals(const LastBlockFinish& f, const float* partial, int ncols, double* tot, int bid, int nb) {
+    int* ticket = reinterpret_cast<int*>(tot);
+    const int t = threadIdx.x;
+    const int g = bid / f.group, ng = (nb + f.group - 1) / f.group;
+    const int gsize = min(f.group, nb - g * f.group);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (t == 0) *ticket = __hip_atomic_fetch_add(&f.counters[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last_of_group = *ticket == gsize - 1;
+    __syncthreads();
+    if (!last_of_group) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (t < ncols) {
+        const float* p = partial + (size_t)g * f.group * ncols + t;
+        double s = 0.0;
+        int r = 0;
+        for (; r + 8 <= gsize; r += 8) {               // eight loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(p + (size_t)(r + k) * ncols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; r < gsize; ++r) s += (double)__hip_atomic_load(p + (size_t)r * ncols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.gsum + (size_t)g * ncols + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_store(&f.counters[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ticket = __hip_atomic_fetch_add(&f.counters[ng], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const bool last_group = *ticket == ng - 1;
+    __syncthreads();
+    if (!last_group) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (t < ncols) {
+        double s = 0.0;
+        int k = 0;
+        for (; k + 4 <= ng; k += 4) {
+            double v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(f.gsum + (size_t)(k + j) * ncols + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j];
+        }
+        for (; k < ng; ++k) s += __hip_atomic_load(f.gsum + (size_t)k * ncols + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot[t] = s;
+    }
+    if (t == 0) __hip_atomic_store(&f.counters[ng], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+}
 template <int MT>
-__global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
+struct NodeBwdLds {
     using GM = StripGeom<MT>;
-    __shared__ __attribute__((aligned(16))) float tu[2][16][GM::LS];     // dUx = dx_tmp
-    __shared__ __attribute__((aligned(16))) float tn[2][16][GM::LS];     // dVn
-    __shared__ __attribute__((aligned(16))) float te[2][16][GM::LS];     // dVe
-    __shared__ __attribute__((aligned(16))) float tp[2][16][GM::LS];     // dpre (residual branch)
-    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    float tu[2][16][GM::LS];     // dUx = dx_tmp
+    float tn[2][16][GM::LS];     // dVn
+    float te[2][16][GM::LS];     // dVe
+    float tp[2][16][GM::LS];     // dpre (residual branch)
+};
+// Workgroup bid of nblk; uses the first 64 * MT threads of the workgroup.
+template <int MT>
+__device__ __forceinline__ void node_bwd_body(const NodeBwdArgs& a, int bid, int nblk, NodeBwdLds<MT>& L) {
+    using GM = StripGeom<MT>;
+    auto& tu = L.tu; auto& tn = L.tn; auto& te = L.te; auto& tp = L.tp;
+    const int t = threadIdx.x;
+    if (t >= 64 * MT) return;                         // whole wavefronts: they take no part in the barriers below
+    const int lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
     const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
     const int H = a.H;
     const bool acol_ok = acol < H;
@@ -538,7 +614,7 @@ __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
     f32x4 na1 = f4zero(), na2 = f4zero();
     const int ntiles = (a.rows + 15) / 16;
     int buf = 0;
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    for (int tl = bid; tl < ntiles; tl += nblk) {
         {
             const int row = tl * 16 + arow;
             const bool valid = row < a.rows && acol_ok;
@@ -599,12 +675,31 @@ __global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
     }
     if (do_next) {
         na1 = red16x4(na1); na2 = red16x4(na2);
+        const bool fin = a.fin.counters != nullptr;
         if (rs == 0 && bcol_ok) {
-            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, na1);
-            st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, na2);
+            float* p = a.next.partial + (size_t)bid * 2 * H + bcol;
+            if (fin) { st4_dev(p, na1); st4_dev(p + H, na2); }
+            else { st4(p, na1); st4(p + H, na2); }
+        }
+        if (fin) {
+            // the last workgroup to arrive finishes the BatchNorm backward of the layer below: d beta = sum dbn,
+            // d gamma = sum dbn * xhat, and their means for the data path
+            double* tot = reinterpret_cast<double*>(&L.tu[0][0][0]);     // tiles are done (barrier inside)
+            if (last_block_totals(a.fin, a.next.partial, 2 * H, tot, bid, nblk) && t < 2 * H) {
+                const double v = tot[t];
+                if (t < H) a.fin.dbeta[t] = (float)v; else a.fin.dgamma[t - H] = (float)v;
+                a.fin.bstats[t] = (float)(v * a.fin.inv_n);
+            }
         }
     }
 }
+
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void k_node_bwd3(NodeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) NodeBwdLds<MT> L;
+    node_bwd_body<MT>(a, (int)blockIdx.x, (int)gridDim.x, L);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM dW[n][k] = sum_row X[row][n] * Y[row][k], db[n] = sum_row X[row][n] (each (problem,
@@ -699,6 +794,31 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_wgrad(int H, TnProblems pr, Reduc
     const int idx = bid - map.seg[k];
     if (k < 4) gemm_tn_body<MT>(H, pr, k, idx, L);
     else reduce_slab_body(jobs.job[k - 4], idx, lds);
+}
+
+// The launch between two layers' edge backward kernels: the node backward of layer l (on the critical path: the
+// edge kernel of layer l-1 needs its dx and, through the in-kernel finish, the BatchNorm-backward means of layer
+// l-1's node BatchNorm), next to it the weight-gradient products that are ready (edge product of layer l, node
+// products of layer l+1) and the reduce jobs that are ready.  1-D grid of 256-thread workgroups:
+// seg[0] .. seg[1] node backward, seg[1 + k] .. products k = 0..3, seg[5 + k] .. reduce jobs k = 0..3.
+struct MidMap {
+    int seg[10];
+};
+template <int MT>
+union MidLds {
+    NodeBwdLds<MT> nb;
+    struct { TnLds<MT> tn; double red[64 * 16]; } wg;
+};
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK, 3) void k_bwd_mid(NodeBwdArgs na, int H, TnProblems pr, ReduceJobs jobs, MidMap map) {
+    __shared__ __attribute__((aligned(16))) MidLds<MT> L;
+    const int bid = blockIdx.x;
+    int k = 0;
+    while (k < 8 && bid >= map.seg[k + 1]) ++k;
+    const int idx = bid - map.seg[k];
+    if (k == 0) node_bwd_body<MT>(na, idx, map.seg[1], L.nb);
+    else if (k < 5) gemm_tn_body<MT>(H, pr, k - 1, idx, L.wg.tn);
+    else reduce_slab_body(jobs.job[k - 5], idx, L.wg.red);
 }
 
 // ------------------------------------------------------------------------------------------------
