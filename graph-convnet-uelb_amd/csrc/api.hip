@@ -194,11 +194,11 @@ int red_grid(const ReduceJobs& jobs) {
 
 int tn_slices(size_t rows) {
     const size_t ntiles = (rows + 15) / 16;
-    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
+    static const int cap = getenv("GCN_TUNE_SLICES") ? atoi(getenv("GCN_TUNE_SLICES")) : 256;
+    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)cap));
 }
 
 constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
-constexpr int kFinGroup = 16;          // workgroups per group of the in-kernel finish of BatchNorm-backward sums
 
 struct LayerBwdWs {
     float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
@@ -570,8 +570,7 @@ struct ModelBwdWs {
     LayerBwdWs lw;
     float *tn_e2, *tn_n2;           // second set of product slabs: layer l's products are written while layer l+1's are reduced
     float *nd2[3];                  // second set of dx_tmp / dVn / dVe: layer l's node backward writes while layer l+1's products read
-    int* fin_counters;              // arrival counters of the in-kernel BatchNorm-backward finish (zero between launches)
-    double* fin_gsum;
+    int* fin_counters;              // arrival counter of the in-kernel BatchNorm-backward finish (zero between launches)
     float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
     int* emb_cnt;
     int head_blk, S_h, emb_blk;
@@ -585,9 +584,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
         w.tn_e2 = b.f((size_t)w.lw.S_e * slab);
         w.tn_n2 = b.f((size_t)w.lw.S_n * 3 * slab);
         for (int k = 0; k < 3; ++k) w.nd2[k] = b.f(p.d.Rn * p.d.H);
-        const size_t ng = (kMaxPartBlocks + kFinGroup - 1) / kFinGroup;
-        w.fin_counters = (int*)b.raw((ng + 1) * sizeof(int));
-        w.fin_gsum = (double*)b.raw(ng * 2 * p.d.H * sizeof(double));
+        w.fin_counters = (int*)b.raw(4 * sizeof(int));
     }
     w.de = b.f(eh);
     w.dx = b.f(p.d.Rn * p.d.H);
@@ -893,7 +890,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     ZeroJobs hz = {};
     hz.p[0] = W.dx; hz.n[0] = nh;
     hz.p[1] = W.lw.bpart_x; hz.n[1] = 2 * (size_t)H;
-    hz.p[2] = reinterpret_cast<float*>(W.fin_counters); hz.n[2] = (kMaxPartBlocks + kFinGroup - 1) / kFinGroup + 1;
+    hz.p[2] = reinterpret_cast<float*>(W.fin_counters); hz.n[2] = 4;
     GCN_PROF_PRE("k_head_bwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
                                                                       dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
@@ -1040,7 +1037,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                                            ndbuf(l, 2), nx);
             static const bool nofin = getenv("GCN_TUNE_NOFIN") != nullptr;      // timing probe: results are then wrong
             if (nx.on && !nofin) {
-                na.fin.counters = W.fin_counters; na.fin.gsum = W.fin_gsum; na.fin.group = kFinGroup;
+                na.fin.counters = W.fin_counters;
                 na.fin.dbeta = nx.G[9]; na.fin.dgamma = nx.G[8]; na.fin.bstats = W.lw.bstats_x; na.fin.inv_n = 1.0 / (double)d.Rn;
             }
             TnProblems pr = {};
@@ -1055,8 +1052,12 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             if (nx.on) bn_finish_job(jobs.job[nj++], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
             if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // top layer only: nj <= 2 there
             jobs.n = nj;
+            static const int midskip = getenv("GCN_TUNE_MIDSKIP") ? atoi(getenv("GCN_TUNE_MIDSKIP")) : 0;   // timing probe: results are then wrong
+            if (midskip & 2) pr.nslices[0] = 0;
+            if (midskip & 4) pr.nslices[1] = pr.nslices[2] = pr.nslices[3] = 0;
+            if (midskip & 8) nj = jobs.n = 0;
             MidMap map = {};
-            int nb = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+            int nb = (midskip & 1) ? 0 : strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
             map.seg[1] = nb;
             for (int k = 0; k < 4; ++k) { nb += pr.nslices[k]; map.seg[2 + k] = nb; }
             for (int k = 0; k < 4; ++k) { if (k < nj) nb += red_blocks(jobs.job[k]); map.seg[6 + k] = nb; }

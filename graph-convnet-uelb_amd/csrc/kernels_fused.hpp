@@ -208,15 +208,12 @@ struct EdgeBwdArgs {
 // dx_tmp, dVe, dVn are written out for the weight-gradient GEMMs; optionally the BatchNorm-backward
 // statistics of layer l-1's node BatchNorm are accumulated from dx_in.
 // ------------------------------------------------------------------------------------------------
-// Finish of a cross-workgroup column sum inside the kernel that produced the partial rows: workgroups are
-// grouped by index; the last workgroup of a group to arrive (device-scope counter) adds the group's rows in index
-// order, and the last group to finish adds the group sums in index order and writes the result.  Which workgroup
-// does the adding depends on timing, what it adds and in which order does not: results are bit-reproducible.
-// counters: ngroups + 1 ints, zero before the launch and zero again after it; gsum: ngroups * ncols doubles.
+// Finish of a cross-workgroup column sum inside the kernel that produced the partial rows: the last workgroup to
+// arrive (device-scope counter) adds all rows in a fixed order and writes the results.  Which workgroup does the
+// adding depends on timing, what it adds and in which order does not: results are bit-reproducible.
+// counters: one int, zero before the launch and zero again after it.
 struct LastBlockFinish {
     int* counters;
-    double* gsum;
-    int group;                 // workgroups per group
     float* dbeta; float* dgamma; float* bstats;      // BatchNorm-backward results of the layer below
     double inv_n;
 };

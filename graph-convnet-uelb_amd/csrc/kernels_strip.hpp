@@ -515,67 +515,58 @@ __device__ __forceinline__ void st4_dev(float* p, const f32x4& v) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) __hip_atomic_store(p + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Called by every thread of every workgroup after workgroup bid of nb has stored its row of `partial` ([nb][ncols], ncols <=
-// the number of calling threads) has been stored with st4_dev.  Returns true in the one workgroup that holds the totals:
-// tot[0 .. ncols) in LDS (ncols doubles, scratch also used for the hand-over of the arrival tickets).
-// Ordering: every value handed between workgroups is stored and loaded at device scope; a workgroup-scope release
-// fence (wait for the stores to be acknowledged) plus the barrier orders them before the arrival counter's
-// device-scope increment, and the reader takes its ticket before it loads.
+// Called by the 64 * MT threads of every workgroup after workgroup bid of nb has stored its row of `partial`
+// ([nb][ncols], ncols <= 32 * MT, a multiple of 4) with st4_dev.  Returns true in the last workgroup to arrive, with
+// the column sums in tot[0 .. ncols) (LDS, 8 * 32 * MT doubles of scratch).  The sums are formed in a fixed order
+// (eight interleaved row groups per column, then a tree over the groups), so which workgroup arrives last does
+// not matter.  Ordering: every value handed between workgroups is stored and loaded at device scope; a
+// workgroup-scope release fence (wait for the stores to be acknowledged) plus the barrier orders them before the
+// device-scope increment of the arrival counter, and the reader takes its ticket before it loads.
+// The loads of one thread are issued in batches of twelve: up to 96 rows the tail costs one ticket and one round of loads.
+template <int MT>
 __device__ __forceinline__ bool last_block_totals(const LastBlockFinish& f, const float* partial, int ncols, double* tot, int bid, int nb) {
+    constexpr int CG = 8 * MT;                 // column groups of four
     int* ticket = reinterpret_cast<int*>(tot);
     const int t = threadIdx.x;
-    const int g = bid / f.group, ng = (nb + f.group - 1) / f.group;
-    const int gsize = min(f.group, nb - g * f.group);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (t == 0) *ticket = __hip_atomic_fetch_add(&f.counters[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) *ticket = __hip_atomic_fetch_add(f.counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const bool last_of_group = *ticket == gsize - 1;
+    const bool last = *ticket == nb - 1;
     __syncthreads();
-    if (!last_of_group) return false;
+    if (!last) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (t < ncols) {
-        const float* p = partial + (size_t)g * f.group * ncols + t;
-        double s = 0.0;
-        int r = 0;
-        for (; r + 8 <= gsize; r += 8) {               // eight loads in flight, added in row order
-            float v[8];
+    const int cg = t % CG, rg = t / CG;        // rg in 0..7
+    const rsrc_t r = make_rsrc(partial, (uint32_t)nb * (uint32_t)ncols * 4u);
+    const uint32_t rowb = (uint32_t)ncols * 4u;
+    const uint32_t base = cg * 4 < ncols ? (uint32_t)cg * 16u : kOob;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    constexpr int NB = 12;                      // rows of this thread's group per batch of loads
+    for (int r0 = rg; r0 < nb; r0 += 8 * NB) {
+        f32x4 v[NB];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = __hip_atomic_load(p + (size_t)(r + k) * ncols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        for (int k = 0; k < NB; ++k) {
+            const int row = r0 + 8 * k;
+            v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, row < nb ? base + (uint32_t)row * rowb : kOob, 0, 16 /* sc1: device scope */));
         }
-        for (; r < gsize; ++r) s += (double)__hip_atomic_load(p + (size_t)r * ncols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(f.gsum + (size_t)g * ncols + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (t == 0) {
-        __hip_atomic_store(&f.counters[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *ticket = __hip_atomic_fetch_add(&f.counters[ng], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const bool last_group = *ticket == ng - 1;
-    __syncthreads();
-    if (!last_group) return false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (t < ncols) {
-        double s = 0.0;
-        int k = 0;
-        for (; k + 4 <= ng; k += 4) {
-            double v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(f.gsum + (size_t)(k + j) * ncols + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < NB; ++k) { a0 += (double)v[k][0]; a1 += (double)v[k][1]; a2 += (double)v[k][2]; a3 += (double)v[k][3]; }
+    }
+    __syncthreads();                           // the ticket word is part of tot
+    double* my = tot + rg * (4 * CG) + cg * 4;
+    my[0] = a0; my[1] = a1; my[2] = a2; my[3] = a3;
+    __syncthreads();
+    for (int sft = 4; sft > 0; sft >>= 1) {
+        if (rg < sft) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += v[j];
+            for (int k = 0; k < 4; ++k) my[k] += my[sft * (4 * CG) + k];
         }
-        for (; k < ng; ++k) s += __hip_atomic_load(f.gsum + (size_t)k * ncols + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tot[t] = s;
+        __syncthreads();
     }
-    if (t == 0) __hip_atomic_store(&f.counters[ng], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    if (t == 0) __hip_atomic_store(f.counters, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
+
 template <int MT>
 struct NodeBwdLds {
     using GM = StripGeom<MT>;
@@ -685,7 +676,7 @@ __device__ __forceinline__ void node_bwd_body(const NodeBwdArgs& a, int bid, int
             // the last workgroup to arrive finishes the BatchNorm backward of the layer below: d beta = sum dbn,
             // d gamma = sum dbn * xhat, and their means for the data path
             double* tot = reinterpret_cast<double*>(&L.tu[0][0][0]);     // tiles are done (barrier inside)
-            if (last_block_totals(a.fin, a.next.partial, 2 * H, tot, bid, nblk) && t < 2 * H) {
+            if (last_block_totals<MT>(a.fin, a.next.partial, 2 * H, tot, bid, nblk) && t < 2 * H) {
                 const double v = tot[t];
                 if (t < H) a.fin.dbeta[t] = (float)v; else a.fin.dgamma[t - H] = (float)v;
                 a.fin.bstats[t] = (float)(v * a.fin.inv_n);
