@@ -29,51 +29,42 @@ __global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Column sums of a partial buffer [nP][ncols] in fp64, fixed order (thread t adds rows t, t+256, ...,
-// then a fixed LDS tree), so results do not depend on scheduling.  One workgroup per 4 columns.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_colsum4(const float* __restrict__ partial, int nP, int ncols, int col,
-                                              double out[4], double* lds /* [256*4] */) {
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int p = threadIdx.x; p < nP; p += blockDim.x) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)p * ncols + col);
-        a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-    }
-    lds[threadIdx.x * 4 + 0] = a0; lds[threadIdx.x * 4 + 1] = a1;
-    lds[threadIdx.x * 4 + 2] = a2; lds[threadIdx.x * 4 + 3] = a3;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lds[threadIdx.x * 4 + k] += lds[(threadIdx.x + s) * 4 + k];
-        }
-        __syncthreads();
-    }
-    out[0] = lds[0]; out[1] = lds[1]; out[2] = lds[2]; out[3] = lds[3];
-    __syncthreads();
-}
-
 // partial [nP][4][H] (sum e, sum e^2, sum x, sum x^2) -> stats [4][H] = mean_e, rstd_e, mean_x, rstd_x.
-// Biased variance, eps 1e-5 (BatchNorm{2,3}d defaults, gcn_layers.py:10,30).  grid = 2 * H/4.
+// Biased variance, eps 1e-5 (BatchNorm{2,3}d defaults, gcn_layers.py:10,30).  grid = 2 * H/4: one workgroup per
+// four columns of one BatchNorm; sum and sum of squares are added in the same pass, in fp64 and in a fixed
+// order: thread t adds rows t, t + 256, ..., a butterfly adds the lanes of each wavefront, thread 0 the wavefronts.
 __global__ __launch_bounds__(GCN_BLOCK) void k_bn_stats_finalize(const float* __restrict__ partial, int nP, int H,
                                                                 double n_e, double n_x, float* __restrict__ stats) {
-    __shared__ double lds[GCN_BLOCK * 4];
+    __shared__ double lds[GCN_WAVES_PER_BLOCK][8];
     const int h4 = H / 4;
     const int which = blockIdx.x / h4;            // 0 = edges, 1 = nodes
     const int col = (blockIdx.x - which * h4) * 4;
-    double s1[4], s2[4];
-    block_colsum4(partial, nP, 4 * H, (2 * which) * H + col, s1, lds);
-    block_colsum4(partial, nP, 4 * H, (2 * which + 1) * H + col, s2, lds);
-    if (threadIdx.x == 0) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* p1 = partial + (2 * which) * H + col;
+    for (int p = threadIdx.x; p < nP; p += GCN_BLOCK) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p1 + (size_t)p * 4 * H);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p1 + (size_t)p * 4 * H + H);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += u[k]; a[4 + k] += v[k]; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += __shfl_xor(a[k], off, 64);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lds[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        double s1 = 0, s2 = 0;
+        for (int w = 0; w < GCN_WAVES_PER_BLOCK; ++w) { s1 += lds[w][k]; s2 += lds[w][4 + k]; }
         const double n = which == 0 ? n_e : n_x;
-        for (int k = 0; k < 4; ++k) {
-            const double mean = s1[k] / n;
-            double var = s2[k] / n - mean * mean;
-            if (var < 0) var = 0;
-            stats[(2 * which) * H + col + k] = (float)mean;
-            stats[(2 * which + 1) * H + col + k] = (float)(1.0 / sqrt(var + (double)GCN_BN_EPS));
-        }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0) var = 0;
+        stats[(2 * which) * H + col + k] = (float)mean;
+        stats[(2 * which + 1) * H + col + k] = (float)(1.0 / sqrt(var + (double)GCN_BN_EPS));
     }
 }
 
