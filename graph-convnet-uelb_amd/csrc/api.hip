@@ -1097,7 +1097,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         if (d.MT > 4) { layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3); nj = 2; }
         else layer_wgrad_jobs(unused, jobs.job[nj++], d, W.lw, W.lw.tn_e, W.lw.tn_n, G + 3);       // node products of layer 0
         ReduceJob& je = jobs.job[nj++];
-        je.partial = W.embpart; je.nP = d.MT > 4 ? W.emb_blk : W.emb_blk * GCN_WAVES_PER_BLOCK; je.ncols = H;
+        je.partial = W.embpart; je.nP = W.emb_blk; je.ncols = H;
         je.rd.n = 1; je.rd.dst[0] = G[2]; je.rd.off[0] = 0; je.rd.off[1] = H;
         jobs.n = nj;
         GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");

@@ -129,8 +129,17 @@ __device__ __forceinline__ void reduce_slab_body(const ReduceJob& J, int colbloc
     if (colblock * bcols >= ncols) return;          // uniform per workgroup
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (col < ncols) {
-        for (int p = pg; p < nP; p += npg) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)p * ncols + col);
+        const float* src = partial + col;
+        int p = pg;
+        for (; p + 3 * npg < nP; p += 4 * npg) {       // four loads in flight, added in row order
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(p + k * npg) * ncols);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0 += v[k][0]; a1 += v[k][1]; a2 += v[k][2]; a3 += v[k][3]; }
+        }
+        for (; p < nP; p += npg) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * ncols);
             a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
         }
     }
@@ -348,12 +357,17 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int 
         }
     }
     tile_red16(acc);
+    // the four wavefronts of the workgroup are added in a fixed order: one partial row per workgroup
+    __shared__ __attribute__((aligned(16))) float wsum[GCN_WAVES_PER_BLOCK][16 * MT];
     if (rs == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int col = 16 * m + 4 * q;
-            if (col < H) *reinterpret_cast<f32x4*>(partial + (size_t)wave * H + col) = acc.v[m];
-        }
+        for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(&wsum[threadIdx.x >> 6][16 * m + 4 * q]) = acc.v[m];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float s = wsum[0][c];
+        for (int w = 1; w < GCN_WAVES_PER_BLOCK; ++w) s += wsum[w][c];
+        partial[(size_t)blockIdx.x * H + c] = s;
     }
 }
 
