@@ -554,9 +554,11 @@ int check_model(const gcn_model_desc* m) {
     return 0;
 }
 
+constexpr int kCountReps = 16;         // replicas of the edge-error counters the strip head spreads its increments over
 struct ModelFwdWs {
     LayerFwdWs lw;
     float* loss_partial;
+    int* count_rep;                 // [kCountReps][2][B*C]
     int head_blk;
 };
 ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
@@ -564,6 +566,7 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     w.lw = carve_fwd_ws(p.d, b);
     w.head_blk = wave_blocks((p.d.Re + 15) / 16);
     w.loss_partial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * 2);
+    w.count_rep = (int*)b.raw((size_t)kCountReps * 2 * p.d.B * p.d.C * sizeof(int));
     return w;
 }
 struct ModelBwdWs {
@@ -608,7 +611,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
 template <int MT, int NHID>
 void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const float* cap,
                      const long long* y_edges, const float* edge_cw, float* y_pred, float* loss_partial, int* counts,
-                     const unsigned long long* rng, int blocks, hipStream_t st) {
+                     int count_reps, const unsigned long long* rng, int blocks, hipStream_t st) {
     if (p.whead) {
         if constexpr (NHID <= 1) {
             if constexpr (MT == 0)
@@ -618,7 +621,8 @@ void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadPara
             else
                 k_head_fwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
                                                                   m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
-                                                                  m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
+                                                                  m->has_labels ? loss_partial : nullptr, counts, count_reps, rng, 1000,
+                                                                  m->p_mlp, m->training);
         }
     } else if constexpr (MT != 0)
     k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
@@ -808,8 +812,13 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const size_t nh = d.Rn * H, eh = d.Re * H;
     float* x_act = saved + p.x_act;
     float* e_act = saved + p.e_act;
-    ZeroJobs ez = {};      // the per-(graph, commodity) counters of edge_error start at zero
-    if (m->has_labels) { ez.p[0] = reinterpret_cast<float*>(err_counts); ez.n[0] = 2 * (size_t)d.B * d.C; }
+    // the per-(graph, commodity) counters of edge_error start at zero; the strip head (H <= 64, at most one hidden
+    // layer) counts into replicas in the workspace, the other heads into the caller's err_counts
+    const bool rep = p.whead && d.MT <= 4;
+    int* counts = rep ? W.count_rep : err_counts;
+    const int nrep = rep ? kCountReps : 1;
+    ZeroJobs ez = {};
+    if (m->has_labels) { ez.p[0] = reinterpret_cast<float*>(counts); ez.n[0] = (size_t)nrep * 2 * d.B * d.C; }
     GCN_PROF_PRE("k_embed_nodes");
     k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act, ez);
     GCN_CHECK_LAUNCH("k_embed_nodes");
@@ -831,12 +840,12 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const EdgeSrc src = make_edge_src(last, nullptr, nullptr, H, m->p_layer, m->training);
     GCN_PROF_PRE("k_head_fwd");
     DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, src, cap, y_edges, edge_cw, y_pred,
-                                                                      W.loss_partial, err_counts, rng, W.head_blk, st))));
+                                                                      W.loss_partial, counts, nrep, rng, W.head_blk, st))));
     GCN_CHECK_LAUNCH("k_head_fwd");
     if (m->has_labels) {
         GCN_PROF_PRE("k_loss_finalize");
-        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, err_counts, d.B * d.C, loss_out,
-                                                 err_flags);
+        k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, counts, d.B * d.C, nrep,
+                                                 loss_out, err_flags);
         GCN_CHECK_LAUNCH("k_loss_finalize");
     }
     return 0;
@@ -1035,8 +1044,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             if (rc) return rc;
             NodeBwdArgs na = node_bwd_args(d, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.lw, ndbuf(l, 0), ndbuf(l, 1),
                                            ndbuf(l, 2), nx);
-            static const bool nofin = getenv("GCN_TUNE_NOFIN") != nullptr;      // timing probe: results are then wrong
-            if (nx.on && !nofin) {
+            if (nx.on) {
                 na.fin.counters = W.fin_counters;
                 na.fin.dbeta = nx.G[9]; na.fin.dgamma = nx.G[8]; na.fin.bstats = W.lw.bstats_x; na.fin.inv_n = 1.0 / (double)d.Rn;
             }
@@ -1052,12 +1060,8 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             if (nx.on) bn_finish_job(jobs.job[nj++], W.lw.bpart_e, npart_e, H, (double)d.Re, nx.G[11], nx.G[10], W.lw.bstats_e);
             if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // top layer only: nj <= 2 there
             jobs.n = nj;
-            static const int midskip = getenv("GCN_TUNE_MIDSKIP") ? atoi(getenv("GCN_TUNE_MIDSKIP")) : 0;   // timing probe: results are then wrong
-            if (midskip & 2) pr.nslices[0] = 0;
-            if (midskip & 4) pr.nslices[1] = pr.nslices[2] = pr.nslices[3] = 0;
-            if (midskip & 8) nj = jobs.n = 0;
             MidMap map = {};
-            int nb = (midskip & 1) ? 0 : strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+            int nb = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
             map.seg[1] = nb;
             for (int k = 0; k < 4; ++k) { nb += pr.nslices[k]; map.seg[2 + k] = nb; }
             for (int k = 0; k < 4; ++k) { if (k < nj) nb += red_blocks(jobs.job[k]); map.seg[6 + k] = nb; }
@@ -1144,7 +1148,7 @@ int gcn_loss_edges_fwd(int B, int V, int C, const float* logits, const long long
         if (hipMemsetAsync(part, 0, (size_t)blocks * 2 * sizeof(float), st) != hipSuccess) return fail(-3, "memset failed");
     }
     GCN_PROF_PRE("k_loss_finalize");
-    k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(part, blocks, counts, B * C, loss_out, err_flags);
+    k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(part, blocks, counts, B * C, 1, loss_out, err_flags);
     GCN_CHECK_LAUNCH("k_loss_finalize");
     return 0;
 }

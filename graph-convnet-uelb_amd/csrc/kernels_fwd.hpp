@@ -217,15 +217,19 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
 
 // loss = sum(w*nll) / sum(w); edge error = 100 * (1 - mean_{b,c} correct/mask) (0/0 -> NaN as in the
 // reference).  out[0] = loss, out[1] = sum w, out[2] = edge error %, flags[b*C+c] = acc < 1.
+// counts: nrep replicas of [2][BC] (correct, mask) counters, added here (the head spreads its increments over
+// the replicas so that they do not queue up on a dozen cache lines).
 __global__ __launch_bounds__(GCN_BLOCK) void k_loss_finalize(const float* __restrict__ loss_partial, int nP,
-                                                            const int* __restrict__ counts, int BC,
+                                                            const int* __restrict__ counts, int BC, int nrep,
                                                             float* __restrict__ out, unsigned char* __restrict__ flags) {
     __shared__ double lds[GCN_BLOCK * 2];
     double a = 0, w = 0;
     for (int p = threadIdx.x; p < nP; p += blockDim.x) { a += loss_partial[(size_t)p * 2]; w += loss_partial[(size_t)p * 2 + 1]; }
     double accsum = 0;
     for (int k = threadIdx.x; k < BC; k += blockDim.x) {
-        const float acc = (float)counts[k] / (float)counts[BC + k];
+        int correct = 0, mask = 0;
+        for (int r = 0; r < nrep; ++r) { correct += counts[(size_t)r * 2 * BC + k]; mask += counts[(size_t)r * 2 * BC + BC + k]; }
+        const float acc = (float)correct / (float)mask;
         flags[k] = acc < 1.0f ? 1 : 0;
         accsum += (double)acc;
     }

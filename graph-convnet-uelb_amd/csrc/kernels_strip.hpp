@@ -818,21 +818,36 @@ __global__ __launch_bounds__(GCN_BLOCK, 3) void k_bwd_mid(NodeBwdArgs na, int H,
 // Phase A builds the head's input tile from EdgeSrc; phase B: wavefront w computes hidden columns 16 w ..,
 // their share of the two output dot products, and the workgroup adds the four shares through LDS.
 // ------------------------------------------------------------------------------------------------
+// The head's input at (row, acol .. acol + 3), in two steps so that the loads of the next tile can be in flight
+// while the current one is processed: head_load issues them (clamped in-range addresses, no predication),
+// head_finish forms the value (zero outside the tensor).
+struct HeadRaw {
+    f32x4 a, b;
+    float cv;
+};
+__device__ __forceinline__ HeadRaw head_load(const EdgeSrc& S, size_t row, size_t rows, int H, int C, int acol, bool acol_ok) {
+    HeadRaw r;
+    r.a = f4zero(); r.b = f4zero(); r.cv = 0.f;
+    const size_t rowc = row < rows ? row : rows - 1;
+    const size_t off = rowc * H + (acol_ok ? acol : 0);
+    if (S.mode == 0) r.a = ld4(S.e_in + off);
+    else if (S.mode == 2) r.cv = S.cap[rowc / C];
+    else { r.a = ld4(S.prev_tmp + off); r.b = ld4(S.prev_in + off); }
+    return r;
+}
 template <int MT>
-__device__ __forceinline__ f32x4 head_src4(const EdgeSrc& S, const float (*cl)[16 * MT], const DropCfg& dc, size_t row, bool valid,
-                                           int H, int C, int acol, int ag) {
-    f32x4 val = f4zero();
-    if (!valid) return val;
-    const size_t off = row * H + acol;
-    if (S.mode == 0) return ld4(S.e_in + off);
-    if (S.mode == 2) return ld4(&cl[CL_WE][acol]) * S.cap[row / C];
-    const f32x4 tp = ld4(S.prev_tmp + off), rin = ld4(S.prev_in + off);
+__device__ __forceinline__ f32x4 head_finish(const EdgeSrc& S, const HeadRaw& r, const float (*cl)[16 * MT], const DropCfg& dc,
+                                             size_t row, bool valid, int acol, int ag) {
+    if (!valid) return f4zero();
+    if (S.mode == 0) return r.a;
+    if (S.mode == 2) return ld4(&cl[CL_WE][acol]) * r.cv;
     const f32x4 pm = ld4(&cl[CL_PMEAN][acol]), pr = ld4(&cl[CL_PRSTD][acol]);
     const f32x4 pg = ld4(&cl[CL_PGAMMA][acol]), pb = ld4(&cl[CL_PBETA][acol]);
+    f32x4 val;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float bn = (tp[k] - pm[k]) * pr[k] * pg[k] + pb[k];
-        val[k] = (bn > 0.f ? bn : 0.f) + rin[k];
+        const float bn = (r.a[k] - pm[k]) * pr[k] * pg[k] + pb[k];
+        val[k] = (bn > 0.f ? bn : 0.f) + r.b[k];
     }
     if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)row), ag);
     return val;
@@ -842,8 +857,8 @@ template <int MT, int NHID>
 __global__ __launch_bounds__(64 * MT) void k_head_fwd3(
     size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, const float* __restrict__ cap, int mask_invalid,
     const long long* __restrict__ y_edges, const float* __restrict__ edge_cw, float* __restrict__ logits,
-    float* __restrict__ loss_partial, int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0,
-    float p, int training) {
+    float* __restrict__ loss_partial, int* __restrict__ counts, int count_reps, const unsigned long long* __restrict__ rng,
+    int stream_id0, float p, int training) {
     static_assert(NHID <= 1, "at most one hidden layer");
     using GM = StripGeom<MT>;
     __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
@@ -869,13 +884,20 @@ __global__ __launch_bounds__(64 * MT) void k_head_fwd3(
     float acc_wn = 0.f, acc_w = 0.f;
     int buf = 0;
     __syncthreads();
+    HeadRaw raw = head_load(src, (size_t)blockIdx.x * 16 + arow, rows, H, C, acol, acol_ok);
     for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        // operands of this tile's epilogue first, then the next tile's input: vector-memory operations retire in
+        // issue order, and the epilogue must not wait for the prefetch
+        const size_t row = tl * 16 + rs;
+        const size_t rowc = row < rows ? row : rows - 1;
+        const float capv = mask_invalid ? cap[rowc / C] : 1.f;
+        const int yv = y_edges != nullptr ? (int)y_edges[rowc] : 0;
         {
-            const size_t row = tl * 16 + arow;
-            st4(&tile[buf][arow][acol], head_src4<MT>(src, cl, sdc, row, row < rows && acol_ok, H, C, acol, ag));
+            const size_t rowa = tl * 16 + arow;
+            st4(&tile[buf][arow][acol], head_finish<MT>(src, raw, cl, sdc, rowa, rowa < rows && acol_ok, acol, ag));
+            if (tl + gridDim.x < ntiles) raw = head_load(src, (tl + gridDim.x) * 16 + arow, rows, H, C, acol, acol_ok);
         }
         __syncthreads();
-        const size_t row = tl * 16 + rs;
         f32x4 h;
         if (NHID) {
             h = strip_gemm<MT>(tile[buf], wf, rs, q) + b1;
@@ -895,25 +917,26 @@ __global__ __launch_bounds__(64 * MT) void k_head_fwd3(
             float l0 = b2_0, l1 = b2_1;
 #pragma unroll
             for (int k = 0; k < MT; ++k) { l0 += red[buf][k][rs][0]; l1 += red[buf][k][rs][1]; }
-            if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+            if (mask_invalid && capv == 0.f) { l0 = -1e9f; l1 = -1e9f; }
             if (voc == 1) {
                 logits[row] = l0;
             } else {
                 logits[row * 2] = l0;
                 logits[row * 2 + 1] = l1;
                 if (y_edges != nullptr) {
-                    const int y = (int)y_edges[row];
+                    const int y = yv;
                     const float mx = fmaxf(l0, l1);
                     const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
                     const float wgt = y ? cw1 : cw0;
                     acc_wn += -wgt * ((y ? l1 : l0) - lse);
                     acc_w += wgt;
                     const int pred = l1 > l0 ? 1 : 0;
-                    if (y + pred > 0) {
+                    if (y + pred > 0 && counts != nullptr) {
                         const int b = (int)(row / BC_stride), c = (int)(row % C);
                         const int BC = (int)(rows / BC_stride) * C;
-                        atomicAdd(&counts[BC + b * C + c], 1);
-                        if (pred == y) atomicAdd(&counts[b * C + c], 1);
+                        int* cnt = counts + (size_t)(blockIdx.x % count_reps) * 2 * BC;     // this workgroup's replica
+                        atomicAdd(&cnt[BC + b * C + c], 1);
+                        if (pred == y) atomicAdd(&cnt[b * C + c], 1);
                     }
                 }
             }
@@ -969,17 +992,29 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     const size_t ntiles = (rows + 15) / 16;
     int buf = 0;
     __syncthreads();
+    HeadRaw raw = head_load(src, (size_t)blockIdx.x * 16 + arow, rows, H, C, acol, acol_ok);
     for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        {
-            const size_t row = tl * 16 + arow;
-            const bool valid = row < rows && acol_ok;
-            const f32x4 val = head_src4<MT>(src, cl, sdc, row, valid, H, C, acol, ag);
-            if (valid && e_stash != nullptr) st4(e_stash + row * H + acol, val);
-            st4(&tile[buf][arow][acol], val);
-        }
-        __syncthreads();
+        // operands of this tile's epilogue first, then the next tile's input (see k_head_fwd3)
         const size_t row = tl * 16 + rs;
         const bool rvalid = row < rows;
+        const size_t rowc = rvalid ? row : rows - 1;
+        const float capv = mask_invalid ? cap[rowc / C] : 1.f;
+        const int yv = has_loss ? (int)y_edges[rowc] : 0;
+        float dy0 = 0.f, dy1 = 0.f;
+        if (dy_pred != nullptr) {
+            if (voc == 1) dy0 = dy_pred[rowc];
+            else { dy0 = dy_pred[rowc * 2]; dy1 = dy_pred[rowc * 2 + 1]; }
+        }
+        const f32x4 ntp = do_next ? ld4(next.tmp + rowc * H + (bcol_ok ? bcol : 0)) : f4zero();
+        {
+            const size_t rowa = tl * 16 + arow;
+            const bool valid = rowa < rows && acol_ok;
+            const f32x4 val = head_finish<MT>(src, raw, cl, sdc, rowa, valid, acol, ag);
+            if (valid && e_stash != nullptr) st4(e_stash + rowa * H + acol, val);
+            st4(&tile[buf][arow][acol], val);
+            if (tl + gridDim.x < ntiles) raw = head_load(src, (tl + gridDim.x) * 16 + arow, rows, H, C, acol, acol_ok);
+        }
+        __syncthreads();
         f32x4 h, dmul;
         if (NHID) {
             const f32x4 pre = strip_gemm<MT>(tile[buf], wf, rs, q) + b1;
@@ -1002,23 +1037,21 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
         __syncthreads();
         float d0 = 0.f, d1 = 0.f;
         if (rvalid) {
-            const bool masked = mask_invalid && cap[row / C] == 0.f;
+            const bool masked = mask_invalid && capv == 0.f;
             if (!masked) {
                 if (has_loss) {
                     float l0 = b2_0, l1 = b2_1;
 #pragma unroll
                     for (int k = 0; k < MT; ++k) { l0 += red[buf][k][rs][0]; l1 += red[buf][k][rs][1]; }
-                    const int y = (int)y_edges[row];
+                    const int y = yv;
                     const float mx = fmaxf(l0, l1);
                     const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
                     const float wgt = (y ? cw1 : cw0) * gl;
                     d0 = wgt * (e0 * inv - (y == 0 ? 1.f : 0.f));
                     d1 = wgt * (e1 * inv - (y == 1 ? 1.f : 0.f));
                 }
-                if (dy_pred != nullptr) {
-                    if (voc == 1) d0 += dy_pred[row];
-                    else { d0 += dy_pred[row * 2]; d1 += dy_pred[row * 2 + 1]; }
-                }
+                d0 += dy0;
+                d1 += dy1;
             }
         }
         if (w == 0 && q == 0) { gb0 += d0; gb1 += d1; }
@@ -1039,7 +1072,6 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
         if (rvalid && bcol_ok) {
             st4(de + row * H + bcol, dv);
             if (do_next) {
-                const f32x4 ntp = ld4(next.tmp + row * H + bcol);
                 const f32x4 nmu = ld4(&cl[CL_PMEAN][bcol]), nrs = ld4(&cl[CL_PRSTD][bcol]);
                 const f32x4 nga = ld4(&cl[CL_PGAMMA][bcol]), nbe = ld4(&cl[CL_PBETA][bcol]);
                 f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};

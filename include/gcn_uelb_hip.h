@@ -102,8 +102,9 @@ size_t gcn_model_saved_floats(const gcn_model_desc* d);
 size_t gcn_model_ws_bytes(const gcn_model_desc* d);
 
 /* y_pred: [B,V,V,C,voc_out].  loss_out[4] = {loss, sum of class weights, edge error %, 0}.
- * err_counts: int32 [2][B*C] (correct, mask) scratch owned by the caller; err_flags: uint8 [B*C],
- * 1 where the (b, c) slice is not perfectly predicted.  Both may be NULL when has_labels == 0. */
+ * err_counts: int32 [2][B*C] (correct, mask) scratch owned by the caller (H <= 64 with mlp_layers <= 2 counts
+ * in the workspace instead and leaves it untouched); err_flags: uint8 [B*C], 1 where the (b, c) slice is not
+ * perfectly predicted.  Both may be NULL when has_labels == 0. */
 int gcn_model_fwd(const gcn_model_desc* d, const float* cap, const float* demand, const long long* x_nodes,
                   const long long* y_edges, const float* edge_cw, const float* const* params,
                   const unsigned long long* rng, float* y_pred, float* loss_out, int* err_counts,
