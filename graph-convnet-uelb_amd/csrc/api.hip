@@ -820,7 +820,8 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     ZeroJobs ez = {};
     if (m->has_labels) { ez.p[0] = reinterpret_cast<float*>(counts); ez.n[0] = (size_t)nrep * 2 * d.B * d.C; }
     GCN_PROF_PRE("k_embed_nodes");
-    k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act, ez);
+    k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act, ez,
+                                            (m->advance_rng && rng) ? const_cast<unsigned long long*>(rng) : nullptr);
     GCN_CHECK_LAUNCH("k_embed_nodes");
     for (int l = 0; l < p.L; ++l) {
         const LayerSaved S = carve_saved(d, saved + p.lsaved + (size_t)l * p.lsaved_each);

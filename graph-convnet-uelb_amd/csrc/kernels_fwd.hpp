@@ -7,8 +7,11 @@
 // one workgroup per (b, i); thread h < H/2 handles channel h of both halves
 __global__ void k_embed_nodes(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
                               const float* __restrict__ demand, const float* __restrict__ emb,
-                              const float* __restrict__ wc, float* __restrict__ x0, ZeroJobs z) {
+                              const float* __restrict__ wc, float* __restrict__ x0, ZeroJobs z,
+                              unsigned long long* __restrict__ rng_advance) {
     zero_fill(z);
+    // first kernel of a forward pass and not a reader of the dropout state: the place to start the next step's masks
+    if (rng_advance != nullptr && blockIdx.x == 0 && threadIdx.x == 0) rng_advance[1] += 1ull;
     const int bi = blockIdx.x;          // b*V + i
     const int b = bi / V;
     const int hh = H / 2;

@@ -14,7 +14,7 @@ import torch
 
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_H = 320
 LAYER_NPARAMS = 12
 
@@ -29,7 +29,7 @@ class ModelDesc(ctypes.Structure):
         ("B", c_int), ("V", c_int), ("C", c_int), ("H", c_int), ("L", c_int),
         ("mlp_layers", c_int), ("voc_out", c_int), ("n_emb", c_int), ("aggregation", c_int),
         ("training", c_int), ("mask_invalid_edges", c_int), ("has_labels", c_int),
-        ("p_layer", c_float), ("p_mlp", c_float),
+        ("p_layer", c_float), ("p_mlp", c_float), ("advance_rng", c_int),
     ]
 
 

@@ -69,7 +69,8 @@ class HipTrainStep:
         self.desc = L.ModelDesc(B=self.B, V=self.V, C=self.C, H=m.hidden_dim, L=m.num_layers, mlp_layers=m.mlp_layers,
                                 voc_out=m.voc_edges_out, n_emb=m.nodes_embedding.num_embeddings,
                                 aggregation=AGG_ID[m.aggregation], training=int(bool(training)), mask_invalid_edges=0,
-                                has_labels=int(bool(self.compute_loss)), p_layer=layer_p, p_mlp=float(m.mlp_edges.dropout_rate))
+                                has_labels=int(bool(self.compute_loss)), p_layer=layer_p, p_mlp=float(m.mlp_edges.dropout_rate),
+                                advance_rng=1)
         self._desc_training = bool(training)
 
     # ------------------------------------------------------------------ data
@@ -98,7 +99,8 @@ class HipTrainStep:
         L.check(rc, "gcn_model_bwd")
 
     def _step_body(self):
-        self.rng[1:2].add_(1)        # new dropout masks every step (device-side, so it is part of the graph)
+        # new dropout masks every step: the forward call advances the step word of self.rng on the device
+        # (advance_rng), so a replayed graph draws fresh masks without a launch of its own
         self._launch()
 
     def step(self):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCN_ABI_VERSION 1
+#define GCN_ABI_VERSION 2
 #define GCN_MAX_H 320
 #define GCN_LAYER_NPARAMS 12
 #define GCN_MAX_MLP_LAYERS 4
@@ -95,6 +95,9 @@ typedef struct gcn_model_desc {
     int has_labels;          /* y_edges / edge_cw given: compute loss and edge-error counters (voc_out == 2) */
     float p_layer;           /* dropout of the conv layers (reference ctor default 0.3) */
     float p_mlp;             /* dropout of the MLP (0.2) */
+    int advance_rng;         /* gcn_model_fwd adds 1 to the step word of `rng` on the device before anything reads it
+                                (a training loop replayed from a HIP graph then needs no launch of its own for that);
+                                gcn_model_bwd never changes it */
 } gcn_model_desc;
 
 int gcn_model_num_params(const gcn_model_desc* d);
