@@ -82,8 +82,10 @@ def test_graph_captured_train_step_matches_autograd_path():
     # training mode: dropout masks differ from replay to replay (the step counter lives in device memory)
     model.train()
     a = step.step()[0].item()
+    n0 = int(step.rng[1].item())
     b = step.step()[0].item()
     assert a != b
+    assert int(step.rng[1].item()) == n0 + 1          # advanced on the device by the forward call itself
 
 
 def test_train_script_runs_on_synthetic_data(tmp_path):
