@@ -473,8 +473,10 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
                 const float* x_in, const float* e_in, const float* const* P, const LayerSaved& S, float* dx,
                 float* de, float* const* G, const LayerBwdWs& W, float* wTbuf, hipStream_t st) {
     const int H = d.H;
-    const float* wT[4];
-    if (int rc = transpose_layer_weights<MT>(P, wTbuf, wT, H, st)) return rc;
+    const float* wT[4] = {P[0], P[2], P[4], P[6]};        // the strip kernels read the weights transposed themselves
+    if constexpr (MT == 0) {
+        if (int rc = transpose_layer_weights<MT>(P, wTbuf, wT, H, st)) return rc;
+    }
     const int nblk_e = wave_blocks((d.Re + 15) / 16), nblk_x = wave_blocks((d.Rn + 15) / 16);
     GCN_PROF_PRE("k_bn_bwd_stats(edges)");
     if constexpr (MT == 0)
@@ -873,8 +875,9 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     const HeadParams hp = head_params(p, P);
     const int hbase = 3 + GCN_LAYER_NPARAMS * p.L;
     const int slab = H * H + H;
-    // transposed copies of every H x H weight used in an "X * W" product of the backward pass (64 per launch)
-    {
+    // wide kernels only: transposed copies of every H x H weight used in an "X * W" product of the backward pass
+    // (64 per launch); the strip kernels read the stored weights transposed
+    if (d.MT > 4) {
         std::vector<std::pair<const float*, float*>> tr;
         const int idx[4] = {0, 2, 4, 6};
         for (int l = 0; l < p.L; ++l)
@@ -1030,8 +1033,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         for (int l = p.L - 1; l >= 0; --l) {
             const LayerSaved S = carve_saved(d, const_cast<float*>(saved) + p.lsaved + (size_t)l * p.lsaved_each);
             const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
-            const float* wT[4];
-            for (int k = 0; k < 4; ++k) wT[k] = W.wT + (size_t)(4 * l + k) * hh2;
+            const float* wT[4] = {LP[0], LP[2], LP[4], LP[6]};      // as stored: node_feat.U, node_feat.V, edge_feat.U, edge_feat.V
             NextLayer nx = {};
             if (l > 0) {
                 const PrevLayer below = prev_of(p, saved, P, l - 1);

@@ -189,7 +189,7 @@ __device__ __forceinline__ void next_bn_accumulate(const NextBn& nb, float (*ncl
 struct EdgeBwdArgs {
     int B, V, C, H, IT, mean_agg;
     float* de;
-    const float* e_tmp; const float* WUt;
+    const float* e_tmp; const float* WUt;      // edge_feat.U: transposed copy (wide kernels) or as stored (strip kernels)
     const float* Vn; const float* Aagg; const float* Dn;
     const float* dx; const float* x_tmp;
     const float* stats;                                   // [4][H] mean_e, rstd_e, mean_x, rstd_x
@@ -223,7 +223,7 @@ struct NodeBwdArgs {
     const float* rowpart; const float* colVe; const float* colVn;
     float* dx; const float* x_tmp;
     const float* mean; const float* rstd; const float* gamma; const float* beta; const float* bstats;
-    const float* WnUt; const float* WnVt; const float* WeVt;
+    const float* WnUt; const float* WnVt; const float* WeVt;   // transposed copies (wide kernels) or as stored (strip kernels)
     float* dxtmp_out; float* dVe_out; float* dVn_out;
     const unsigned long long* rng; int sid_x; float p; int training;
     NextBn next;

@@ -75,6 +75,20 @@ __device__ __forceinline__ void strip_wfrag(f32x4 (&wf)[MT], const float* __rest
     }
 }
 
+// The same fragment of the TRANSPOSE of W, read from W as stored: element t of wf[s] is W[16s + 4q + t][16w + rs]
+// (four 32-bit loads, the 16 lanes of a row read 64 contiguous bytes).  The backward kernels multiply by W^T; the
+// weights are a few KiB and sit in L2, so no transposed copies are made.
+template <int MT>
+__device__ __forceinline__ void strip_wfrag_t(f32x4 (&wf)[MT], const float* __restrict__ W, int H, int w, int rs, int q) {
+    const rsrc_t r = make_rsrc(W, (uint32_t)H * H * 4);
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+        const int n = 16 * w + rs, k = 16 * s + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[s][t] = bld1(r, (n < H && k + t < H) ? (uint32_t)((k + t) * H + n) * 4 : kOob);
+    }
+}
+
 // Sum over the 16 lanes of a row (all 16 lanes receive the sum) of four values at once with DPP-fused adds:
 // four independent chains interleaved, so a result is read by a DPP operand no sooner than three
 // instructions after it is written (the hardware needs two); the leading s_nop covers the producer of the inputs.
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
     load_vnj(b, c, jt);
     __builtin_amdgcn_sched_barrier(0);       // keep the instruction scheduler from moving these past the loads below
     f32x4 wf[MT];
-    strip_wfrag<MT>(wf, a.WUt, H, w, rs, q);
+    strip_wfrag_t<MT>(wf, a.WUt, H, w, rs, q);          // a.WUt: edge_feat.U weight as stored
     __builtin_amdgcn_sched_barrier(0);
     f32x4 cve = f4zero(), cvn = f4zero();
     while (true) {
@@ -595,9 +609,9 @@ __device__ __forceinline__ void node_bwd_body(const NodeBwdArgs& a, int bid, int
         xm1 = ld4(a.bstats + acol); xm2 = ld4(a.bstats + H + acol);
     }
     f32x4 wfu[MT], wfn[MT], wfe[MT];
-    strip_wfrag<MT>(wfu, a.WnUt, H, w, rs, q);
-    strip_wfrag<MT>(wfn, a.WnVt, H, w, rs, q);
-    strip_wfrag<MT>(wfe, a.WeVt, H, w, rs, q);
+    strip_wfrag_t<MT>(wfu, a.WnUt, H, w, rs, q);        // the three weights as stored
+    strip_wfrag_t<MT>(wfn, a.WnVt, H, w, rs, q);
+    strip_wfrag_t<MT>(wfe, a.WeVt, H, w, rs, q);
     f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
     if (do_next && bcol_ok) { nmu = ld4(a.next.mean + bcol); nrs = ld4(a.next.rstd + bcol); nga = ld4(a.next.gamma + bcol); nbe = ld4(a.next.beta + bcol); }
     const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
@@ -979,7 +993,7 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
     const bool do_next = next.tmp != nullptr;
     f32x4 wf[MT], wft[MT];
-    if (NHID) { strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q); strip_wfrag<MT>(wft, hidWt, H, w, rs, q); }
+    if (NHID) { strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q); strip_wfrag_t<MT>(wft, hp.hidW[0], H, w, rs, q); }
     const f32x4 b1 = (NHID && bcol_ok) ? ld4(hp.hidB[0] + bcol) : f4zero();
     const f32x4 w0 = bcol_ok ? ld4(hp.outW + bcol) : f4zero();
     const f32x4 w1 = (bcol_ok && voc > 1) ? ld4(hp.outW + H + bcol) : f4zero();
