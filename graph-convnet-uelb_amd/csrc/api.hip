@@ -1080,22 +1080,25 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             layer_wgrad_jobs(jobs.job[nj++], unused, d, W.lw, tn_e_of(0), tn_n_of(0), G + 3);
             if (p.L > 1) layer_wgrad_jobs(unused, jobs.job[nj++], d, W.lw, tn_e_of(1), tn_n_of(1), G + 3 + GCN_LAYER_NPARAMS);
             jobs.n = nj;
-            WgradMap map = {};
+            TailMap map = {};
             int nb = 0;
             for (int k = 0; k < 4; ++k) { map.seg[k] = nb; nb += pr.nslices[k]; }
             for (int k = 0; k < 4; ++k) { map.seg[4 + k] = nb; if (k < nj) nb += red_blocks(jobs.job[k]); }
-            map.seg[8] = nb;
-            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad(tail)", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
+            map.seg[8] = nb; nb += W.emb_blk;
+            map.seg[9] = nb; nb += d.B * d.V;
+            map.seg[10] = nb;
+            const EmbedEdgesArgs ee = {d.Re, d.C, cap, W.de, W.embpart};
+            const EmbedRowsumArgs er = {d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt};
+            DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_bwd_tail", (k_bwd_tail<MT>), nb, GCN_BLOCK, H, pr, jobs, ee, er, map));
         }
     }
-    // embeddings
-    GCN_PROF_PRE("k_embed_bwd_edges");
-    if (d.MT > 4)
+    // embeddings (H <= 64: partial sums and row sums were part of the tail launch)
+    if (d.MT > 4) {
+        GCN_PROF_PRE("k_embed_bwd_edges");
         k_colsum_w<false><<<W.emb_blk, 256, 0, st>>>(d.Re, H, d.C, W.de, nullptr, nullptr, nullptr, nullptr, nullptr, cap, W.embpart,
                                                      nullptr, 0, 0.f, 0);
-    else
-        DISPATCH_MT(d.MT, if constexpr (MT != 0) (k_embed_bwd_edges<MT><<<W.emb_blk, GCN_BLOCK, 0, st>>>(d.Re, d.C, H, cap, W.de, W.embpart)));
-    GCN_CHECK_LAUNCH("k_embed_bwd_edges");
+        GCN_CHECK_LAUNCH("k_embed_bwd_edges");
+    }
     {
         // one reduce launch: products of layer 0 (slab set 0) and the edge-embedding gradient
         ReduceJobs jobs = {};
@@ -1112,9 +1115,12 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0, edge embedding)");
     }
     {
-        GCN_PROF_PRE("k_embed_bwd_rowsum");
-        k_embed_bwd_rowsum<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt);
-        GCN_CHECK_LAUNCH("k_embed_bwd_rowsum");
+        if (d.MT > 4) {
+            GCN_PROF_PRE("k_embed_bwd_rowsum");
+            const EmbedRowsumArgs er = {d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt};
+            k_embed_bwd_rowsum<<<d.B * d.V, 64, 0, st>>>(er);
+            GCN_CHECK_LAUNCH("k_embed_bwd_rowsum");
+        }
         GCN_PROF_PRE("k_embed_bwd_nodes");
         // many short chains of dependent loads: wide workgroups (hh * parts threads) keep the chains short
         const int eb_threads = std::max(GCN_BLOCK, std::min(1024, (1024 / std::max(H / 2, 1)) * (H / 2)));

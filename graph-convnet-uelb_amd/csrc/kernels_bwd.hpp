@@ -338,11 +338,11 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_bwd(
 // Embedding backward.  d w_e[h] = sum_rows cap[row / C] * de0[row][h]   (per-wavefront partials [nwaves][H])
 // ------------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int C, int H, const float* __restrict__ cap,
-                                                              const float* __restrict__ de0, float* __restrict__ partial) {
+__device__ __forceinline__ void embed_bwd_edges_body(size_t rows, int C, int H, const float* __restrict__ cap,
+                                                     const float* __restrict__ de0, float* __restrict__ partial, int bid, int nblk) {
     const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * GCN_WAVES_PER_BLOCK;
+    const int wave = bid * GCN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int nwaves = nblk * GCN_WAVES_PER_BLOCK;
     Tile<MT> acc;
     tile_zero(acc);
     const size_t ntiles = (rows + 15) / 16;
@@ -367,8 +367,14 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int 
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         float s = wsum[0][c];
         for (int w = 1; w < GCN_WAVES_PER_BLOCK; ++w) s += wsum[w][c];
-        partial[(size_t)blockIdx.x * H + c] = s;
+        partial[(size_t)bid * H + c] = s;
     }
+}
+
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int C, int H, const float* __restrict__ cap,
+                                                              const float* __restrict__ de0, float* __restrict__ partial) {
+    embed_bwd_edges_body<MT>(rows, C, H, cap, de0, partial, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Node embedding backward in two small launches.
@@ -377,31 +383,43 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_embed_bwd_edges(size_t rows, int 
 //   k_embed_bwd_nodes : dEmb[v][h] = (1/C) * sum_bi cnt[bi][v] * g1[bi][h];  d w_c[h] = sum_bi g2[bi][h]
 // (x0[b,i,c,:H/2] is the mean over c' of Emb[x_nodes[b,i,c']], gcn_model.py:78-84).  Fixed summation
 // order, so reproducible.
-__global__ void k_embed_bwd_rowsum(int V, int C, int H, int n_emb, const long long* __restrict__ x_nodes,
-                                   const float* __restrict__ demand, const float* __restrict__ dx0,
-                                   float* __restrict__ g, int* __restrict__ cnt) {
-    const int bi = blockIdx.x, b = bi / V, hh = H / 2;
+struct EmbedRowsumArgs {
+    int V, C, H, n_emb;
+    const long long* x_nodes; const float* demand; const float* dx0;
+    float* g; int* cnt;
+};
+// one workgroup per (b, i); four independent chains of loads per sum (c = k, k + 4, ... added in that order, then
+// the four chains in order)
+__device__ __forceinline__ void embed_bwd_rowsum_body(const EmbedRowsumArgs& a, int bi) {
+    const int C = a.C, H = a.H, b = bi / a.V, hh = H / 2;
+    const float* d0 = a.dx0 + (size_t)bi * C * H;
+    const float* dem = a.demand + (size_t)b * C;
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
-        float s = 0.f;
-        if (h < hh) {
-            for (int c = 0; c < C; ++c) s += dx0[((size_t)bi * C + c) * H + h];
-        } else {
-            for (int c = 0; c < C; ++c) s += demand[(size_t)b * C + c] * dx0[((size_t)bi * C + c) * H + h];
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        for (; c + 4 <= C; c += 4) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = d0[(size_t)(c + k) * H + h] * (h < hh ? 1.f : dem[c + k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += v[k];
         }
-        g[(size_t)bi * H + h] = s;
+        for (int k = 0; c < C; ++c, ++k) s[k] += d0[(size_t)c * H + h] * (h < hh ? 1.f : dem[c]);
+        a.g[(size_t)bi * H + h] = (s[0] + s[1]) + (s[2] + s[3]);
     }
-    for (int v = threadIdx.x; v < n_emb; v += blockDim.x) {
+    const long long* xn = a.x_nodes + (size_t)bi * C;
+    for (int v = threadIdx.x; v < a.n_emb; v += blockDim.x) {
         int n = 0;
+#pragma unroll 8
         for (int c = 0; c < C; ++c) {
-            long long idx = x_nodes[(size_t)bi * C + c];
-            idx = idx < 0 ? 0 : (idx >= n_emb ? n_emb - 1 : idx);
+            long long idx = xn[c];
+            idx = idx < 0 ? 0 : (idx >= a.n_emb ? a.n_emb - 1 : idx);
             n += (idx == v);
         }
-        cnt[(size_t)bi * n_emb + v] = n;
+        a.cnt[(size_t)bi * a.n_emb + v] = n;
     }
 }
-
-// one workgroup per embedding row v (blockIdx.x < n_emb) plus one (blockIdx.x == n_emb) for d w_c
+__global__ void k_embed_bwd_rowsum(EmbedRowsumArgs a) { embed_bwd_rowsum_body(a, (int)blockIdx.x); }
 __global__ __launch_bounds__(1024) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
                                                               const int* __restrict__ cnt, float* __restrict__ demb,
                                                               float* __restrict__ dwc) {

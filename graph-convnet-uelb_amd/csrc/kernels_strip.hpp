@@ -801,6 +801,30 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_wgrad(int H, TnProblems pr, Reduc
     else reduce_slab_body(jobs.job[k - 4], idx, lds);
 }
 
+// Tail of the backward pass in one launch: the last products and slab reductions (as k_wgrad) next to the two
+// embedding kernels that are ready at the same point.  seg[0..3] products, seg[4..7] reduce jobs, seg[8] partial sums
+// of the edge-embedding gradient, seg[9] row sums of the node-embedding gradient, seg[10] = grid.
+struct TailMap {
+    int seg[11];
+};
+struct EmbedEdgesArgs {
+    size_t rows; int C;
+    const float* cap; const float* de0; float* partial;
+};
+template <int MT>
+__global__ __launch_bounds__(GCN_BLOCK) void k_bwd_tail(int H, TnProblems pr, ReduceJobs jobs, EmbedEdgesArgs ee, EmbedRowsumArgs er, TailMap map) {
+    __shared__ __attribute__((aligned(16))) TnLds<MT> L;
+    __shared__ double lds[64 * 16];
+    const int bid = blockIdx.x;
+    int k = 0;
+    while (k < 9 && bid >= map.seg[k + 1]) ++k;
+    const int idx = bid - map.seg[k];
+    if (k < 4) gemm_tn_body<MT>(H, pr, k, idx, L);
+    else if (k < 8) reduce_slab_body(jobs.job[k - 4], idx, lds);
+    else if (k == 8) embed_bwd_edges_body<MT>(ee.rows, ee.C, H, ee.cap, ee.de0, ee.partial, idx, map.seg[9] - map.seg[8]);
+    else embed_bwd_rowsum_body(er, idx);
+}
+
 // The launch between two layers' edge backward kernels: the node backward of layer l (on the critical path: the
 // edge kernel of layer l-1 needs its dx and, through the in-kernel finish, the BatchNorm-backward means of layer
 // l-1's node BatchNorm), next to it the weight-gradient products that are ready (edge product of layer l, node
