@@ -1110,23 +1110,31 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         je.partial = W.embpart; je.nP = W.emb_blk; je.ncols = H;
         je.rd.n = 1; je.rd.dst[0] = G[2]; je.rd.off[0] = 0; je.rd.off[1] = H;
         jobs.n = nj;
-        GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");
-        k_reduce_slabs<<<dim3(red_grid(jobs), nj, 1), GCN_BLOCK, 0, st>>>(jobs);
-        GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0, edge embedding)");
-    }
-    {
+        // many short chains of dependent loads in the node-embedding finish: wide workgroups (hh * parts threads)
+        const int eb_threads = std::max(GCN_BLOCK, std::min(1024, (1024 / std::max(H / 2, 1)) * (H / 2)));
         if (d.MT > 4) {
+            GCN_PROF_PRE("k_reduce_slabs(layer 0, edge embedding)");
+            k_reduce_slabs<<<dim3(red_grid(jobs), nj, 1), GCN_BLOCK, 0, st>>>(jobs);
+            GCN_CHECK_LAUNCH("k_reduce_slabs(layer 0, edge embedding)");
             GCN_PROF_PRE("k_embed_bwd_rowsum");
             const EmbedRowsumArgs er = {d.V, d.C, H, m->n_emb, x_nodes, demand, W.dx, W.emb_g, W.emb_cnt};
             k_embed_bwd_rowsum<<<d.B * d.V, 64, 0, st>>>(er);
             GCN_CHECK_LAUNCH("k_embed_bwd_rowsum");
+            GCN_PROF_PRE("k_embed_bwd_nodes");
+            k_embed_bwd_nodes<<<m->n_emb + 1, eb_threads, eb_threads * sizeof(double), st>>>(d.B * d.V, d.C, H, m->n_emb, W.emb_g,
+                                                                                        W.emb_cnt, G[0], G[1]);
+            GCN_CHECK_LAUNCH("k_embed_bwd_nodes");
+        } else {
+            // H <= 64: the last reductions and the node-embedding finish need nothing from each other: one launch
+            FinalMap map = {};
+            int nb = 0;
+            for (int k = 0; k < 4; ++k) { map.rseg[k] = nb; if (k < nj) nb += red_blocks(jobs.job[k]); }
+            map.rseg[4] = nb;
+            GCN_PROF_PRE("k_bwd_final");
+            k_bwd_final<<<m->n_emb + 1 + nb, eb_threads, std::max(eb_threads, 1024) * sizeof(double), st>>>(
+                d.B * d.V, d.C, H, m->n_emb, W.emb_g, W.emb_cnt, G[0], G[1], jobs, map);
+            GCN_CHECK_LAUNCH("k_bwd_final");
         }
-        GCN_PROF_PRE("k_embed_bwd_nodes");
-        // many short chains of dependent loads: wide workgroups (hh * parts threads) keep the chains short
-        const int eb_threads = std::max(GCN_BLOCK, std::min(1024, (1024 / std::max(H / 2, 1)) * (H / 2)));
-        k_embed_bwd_nodes<<<m->n_emb + 1, eb_threads, eb_threads * sizeof(double), st>>>(d.B * d.V, d.C, H, m->n_emb, W.emb_g,
-                                                                                    W.emb_cnt, G[0], G[1]);
-        GCN_CHECK_LAUNCH("k_embed_bwd_nodes");
     }
     return 0;
 }

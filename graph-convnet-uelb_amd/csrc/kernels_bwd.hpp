@@ -420,12 +420,10 @@ __device__ __forceinline__ void embed_bwd_rowsum_body(const EmbedRowsumArgs& a, 
     }
 }
 __global__ void k_embed_bwd_rowsum(EmbedRowsumArgs a) { embed_bwd_rowsum_body(a, (int)blockIdx.x); }
-__global__ __launch_bounds__(1024) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
-                                                              const int* __restrict__ cnt, float* __restrict__ demb,
-                                                              float* __restrict__ dwc) {
-    extern __shared__ double lds_d[];     // [blockDim.x]
+__device__ __forceinline__ void embed_bwd_nodes_body(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
+                                                     const int* __restrict__ cnt, float* __restrict__ demb,
+                                                     float* __restrict__ dwc, int v, double* lds_d /* [blockDim.x] */) {
     const int hh = H / 2;
-    const int v = blockIdx.x;
     const int parts = blockDim.x / hh;
     const int h = threadIdx.x % hh, part = threadIdx.x / hh;
     double acc = 0;
@@ -447,6 +445,30 @@ __global__ __launch_bounds__(1024) void k_embed_bwd_nodes(int nbi, int C, int H,
         if (v < n_emb) demb[(size_t)v * hh + h] = (float)(sacc / (double)C);
         else dwc[h] = (float)sacc;
     }
+}
+__global__ __launch_bounds__(1024) void k_embed_bwd_nodes(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
+                                                              const int* __restrict__ cnt, float* __restrict__ demb,
+                                                              float* __restrict__ dwc) {
+    extern __shared__ double lds_d[];     // [blockDim.x]
+    embed_bwd_nodes_body(nbi, C, H, n_emb, g, cnt, demb, dwc, (int)blockIdx.x, lds_d);
+}
+// The same next to slab reductions, which need nothing from it: workgroups 0 .. n_emb finish the node embedding,
+// the others run reduce jobs (first 256 threads; the rest of such a workgroup leaves at once).
+// rseg[k] .. rseg[k + 1]: workgroups of reduce job k, counted from n_emb + 1.
+struct FinalMap {
+    int rseg[5];
+};
+__global__ __launch_bounds__(1024) void k_bwd_final(int nbi, int C, int H, int n_emb, const float* __restrict__ g,
+                                                        const int* __restrict__ cnt, float* __restrict__ demb,
+                                                        float* __restrict__ dwc, ReduceJobs jobs, FinalMap map) {
+    extern __shared__ double lds_d[];     // [max(blockDim.x, 1024)]
+    const int bid = blockIdx.x;
+    if (bid <= n_emb) { embed_bwd_nodes_body(nbi, C, H, n_emb, g, cnt, demb, dwc, bid, lds_d); return; }
+    if (threadIdx.x >= GCN_BLOCK) return;
+    const int r = bid - (n_emb + 1);
+    int k = 0;
+    while (k < 3 && r >= map.rseg[k + 1]) ++k;
+    reduce_slab_body(jobs.job[k], r - map.rseg[k], lds_d);
 }
 
 // ------------------------------------------------------------------------------------------------
