@@ -225,34 +225,30 @@ __global__ __launch_bounds__(GCN_BLOCK) void k_head_fwd(
 __global__ __launch_bounds__(GCN_BLOCK) void k_loss_finalize(const float* __restrict__ loss_partial, int nP,
                                                             const int* __restrict__ counts, int BC, int nrep,
                                                             float* __restrict__ out, unsigned char* __restrict__ flags) {
-    __shared__ double lds[GCN_BLOCK * 2];
+    __shared__ double lds[GCN_WAVES_PER_BLOCK][3];
     double a = 0, w = 0;
-    for (int p = threadIdx.x; p < nP; p += blockDim.x) { a += loss_partial[(size_t)p * 2]; w += loss_partial[(size_t)p * 2 + 1]; }
+    for (int p = threadIdx.x; p < nP; p += GCN_BLOCK) { a += loss_partial[(size_t)p * 2]; w += loss_partial[(size_t)p * 2 + 1]; }
     double accsum = 0;
-    for (int k = threadIdx.x; k < BC; k += blockDim.x) {
+    for (int k = threadIdx.x; k < BC; k += GCN_BLOCK) {
         int correct = 0, mask = 0;
+#pragma unroll 4
         for (int r = 0; r < nrep; ++r) { correct += counts[(size_t)r * 2 * BC + k]; mask += counts[(size_t)r * 2 * BC + BC + k]; }
         const float acc = (float)correct / (float)mask;
         flags[k] = acc < 1.0f ? 1 : 0;
         accsum += (double)acc;
     }
-    lds[threadIdx.x * 2] = a; lds[threadIdx.x * 2 + 1] = w;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2]; lds[threadIdx.x * 2 + 1] += lds[(threadIdx.x + s) * 2 + 1]; }
-        __syncthreads();
+    // fixed order: butterfly over the lanes of each wavefront, then the wavefronts in order
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64); w += __shfl_xor(w, off, 64); accsum += __shfl_xor(accsum, off, 64);
     }
-    const double tot_a = lds[0], tot_w = lds[1];
+    if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6][0] = a; lds[threadIdx.x >> 6][1] = w; lds[threadIdx.x >> 6][2] = accsum; }
     __syncthreads();
-    lds[threadIdx.x * 2] = accsum;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) lds[threadIdx.x * 2] += lds[(threadIdx.x + s) * 2];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
+        double tot_a = 0, tot_w = 0, tot_acc = 0;
+        for (int k = 0; k < GCN_WAVES_PER_BLOCK; ++k) { tot_a += lds[k][0]; tot_w += lds[k][1]; tot_acc += lds[k][2]; }
         out[0] = (float)(tot_a / tot_w);
         out[1] = (float)tot_w;
-        out[2] = (float)(100.0 * (1.0 - lds[0] / (double)BC));
+        out[2] = (float)(100.0 * (1.0 - tot_acc / (double)BC));
     }
 }
