@@ -201,7 +201,10 @@ def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
 
 
 @pytest.mark.parametrize("H,L,mlp_layers,voc", [(80, 2, 2, 2), (128, 3, 2, 2), (300, 2, 2, 2), (96, 2, 1, 2), (72, 2, 2, 1),
-                                                 (16, 30, 2, 2), (32, 17, 3, 2)])
+                                                 (16, 30, 2, 2), (32, 17, 3, 2),
+                                                 # corner cases of the backward schedule: one or two layers, no hidden
+                                                 # MLP layer, the deepest MLP, the edge-score head
+                                                 (16, 1, 1, 2), (32, 2, 1, 1), (64, 3, 4, 2), (8, 1, 2, 1), (64, 2, 3, 2)])
 def test_wide_model_matches_oracle(H, L, mlp_layers, voc):
     """Whole model (embedding, L layers, edge MLP, loss) against the oracle in float64: hidden sizes above 64, and
     stacks deeper than 15 layers (the 30 of the large synthetic configuration)."""
