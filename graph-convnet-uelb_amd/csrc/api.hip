@@ -694,6 +694,11 @@ PrevLayer prev_of(const ModelPlan& p, const float* saved, const float* const* P,
 extern "C" {
 
 int gcn_abi_version(void) { return GCN_ABI_VERSION; }
+#ifdef GCN_PHASE_TRACE
+extern "C" int gcn_phase_trace_read(unsigned long long* host_out /* [512] */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_trace), 512 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 const char* gcn_last_error(void) { return g_err; }
 
 static void prof_clear() {

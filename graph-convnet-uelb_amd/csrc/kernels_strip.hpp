@@ -112,6 +112,13 @@ __device__ __forceinline__ f32x4 red16x4(f32x4 v) {
 // epilogue operands of step n are requested before the phase-A operands of step n+1).
 // partial layout [gridDim.x][4][H], written by the lanes that own each column.
 // ------------------------------------------------------------------------------------------------
+#ifdef GCN_PHASE_TRACE
+// Build-time option for measurements only: wavefront 0 of workgroup 0 stamps the shader clock at phase boundaries.
+__device__ unsigned long long g_phase_trace[512];
+#define GCN_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tstep < 16) g_phase_trace[tstep * 8 + (slot)] = clock64(); } while (0)
+#else
+#define GCN_STAMP(slot) do { } while (0)
+#endif
 // ONE_TILE: V <= 16, every step ends its unit (no branch around the unit-end code).
 template <int MT, int MODE, bool ONE_TILE>
 __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
@@ -177,7 +184,11 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
     f32x4 uxv = bld4(make_rsrc(rowp(a.Ux, u), hb), voffN);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 num = f4zero(), den = f4zero(), s1 = f4zero(), s2 = f4zero();
+#ifdef GCN_PHASE_TRACE
+    int tstep = 0;
+#endif
     while (true) {
+        GCN_STAMP(0);
         const uint32_t erow0 = (uint32_t)(bi * V + jt * 16) * C + c;
         const uint32_t nbytes = tile_bytes(jt);
         // ---- phase A of the current step
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
             st4(&tile[buf][arow][acol], val);
         }
         // ---- next step's coordinates
+        GCN_STAMP(1);
         const bool unit_end = ONE_TILE || jt + 1 == njt;
         int nu = u, njt2 = jt + 1, nbi = bi, nc = c, nb = b, ni = i;
         if (unit_end) {
@@ -219,9 +231,20 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
         const f32x4 vej = bld4(make_rsrc(rowp(a.Ve, n0), (a.probe & 8) ? 0u : nbytes), voffB);
         const f32x4 vnj = bld4(make_rsrc(rowp(a.Vn, n0), (a.probe & 8) ? 0u : nbytes), voffB);
         load_raw(nbi, nc, njt2);
+        GCN_STAMP(2);
         __syncthreads();
+        GCN_STAMP(3);
         // ---- phase B
-        const f32x4 et = strip_gemm<MT>(tile[buf], wf, rs, q) + (vei + bu) + vej;
+        f32x4 et = strip_gemm<MT>(tile[buf], wf, rs, q);
+#ifdef GCN_PHASE_TRACE
+        asm volatile("" : "+v"(et));
+        GCN_STAMP(4);
+#endif
+        et += (vei + bu) + vej;
+#ifdef GCN_PHASE_TRACE
+        asm volatile("" : "+v"(et));
+        GCN_STAMP(5);
+#endif
         bst4(make_rsrc(rowpw(a.e_tmp, erow0), (a.probe & 4) ? 0u : nbytes), voffB, et);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -249,6 +272,10 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
             psx1 += xt; psx2 += xt * xt;
             num = f4zero(); den = f4zero();
         }
+        GCN_STAMP(6);
+#ifdef GCN_PHASE_TRACE
+        ++tstep;
+#endif
         if (!more) break;
         u = nu; jt = njt2; bi = nbi; c = nc; b = nb; i = ni; vei = vei_n; uxv = uxv_n;
     }

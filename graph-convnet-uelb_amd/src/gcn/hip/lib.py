@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 import torch
 
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
+LIB_PATH = os.environ.get("GCN_UELB_LIB") or os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
 ABI_VERSION = 2
 MAX_H = 320
 LAYER_NPARAMS = 12
