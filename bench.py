@@ -251,6 +251,10 @@ def main():
     if dist is not None:
         for p in model.parameters():
             bcast(p.data)
+        # class weights: one set for the whole job (rank 0's), as the trainer uses global weights for every shard
+        cw = torch.from_numpy(np.asarray(batch["edge_cw"], dtype=np.float32)).to(device)
+        bcast(cw)
+        batch["edge_cw"] = cw.cpu().numpy()
     _stage("parameters broadcast")
     step = HipTrainStep(model, B, device, use_graph=not args.no_graph)
     step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
