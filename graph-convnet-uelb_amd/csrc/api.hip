@@ -435,7 +435,14 @@ void layer_tn_problems(TnProblems& pr, const Dims& d, const LayerBwdWs& W, const
 template <int MT>
 int launch_tn(int H, const TnProblems& pr, int nprob, int max_slices, hipStream_t st) {
     GCN_PROF_PRE("k_gemm_tn");
-    if constexpr (MT == 0) k_gemm_tn_w<<<dim3(max_slices, ((H + 15) / 16 + 3) / 4, nprob), 256, 0, st>>>(H, pr);
+    if constexpr (MT == 0) {
+        // 86 KiB of LDS per workgroup: above the 64 KiB a kernel gets without asking (set per call: the attribute
+        // belongs to the current device)
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_w),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TnWideLds));
+        if (attr != hipSuccess) return fail(-3, "k_gemm_tn_w: cannot reserve %zu bytes of LDS", sizeof(TnWideLds));
+        k_gemm_tn_w<<<dim3(max_slices, 1, nprob), 512, sizeof(TnWideLds), st>>>(H, pr);
+    }
     else k_gemm_tn2<MT><<<dim3(max_slices, 1, nprob), 64 * MT, 0, st>>>(H, pr);
     GCN_CHECK_LAUNCH("k_gemm_tn");
     return 0;

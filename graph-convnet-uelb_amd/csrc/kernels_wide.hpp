@@ -509,63 +509,101 @@ __global__ __launch_bounds__(256) void k_node_bwd_w(NodeBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight-gradient products (TnProblems, slab layout as k_gemm_tn2): grid (slices, column-block quads, problems);
-// wavefront w of workgroup (slice, y, prob) accumulates dW rows 16 (4 y + w) .. + 15.
+// Weight-gradient products (TnProblems, slab layout as k_gemm_tn2), one workgroup per row slice computing the whole
+// H x H slab: 8 wavefronts, wavefront
+// (wr, wc) = (w / 2, w % 2) holds the 5 x 10 blocks of 16 x 16 outputs with dW rows 80 wr .. and columns 160 wc ..
+// in registers (200 accumulators), so every row of X and Y is read from memory once per product and each LDS operand
+// feeds 5 or 10 MFMAs.  Rows are staged in chunks of 16 through two LDS buffers (one barrier per chunk) while the
+// next chunk's loads are in flight.  grid (slices, 1, problems), 512 threads.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gemm_tn_w(int H, TnProblems pr) {
-    constexpr int LT = GCN_WIDE_MAX_H + 16;
-    __shared__ __attribute__((aligned(16))) float tx[16][64 + 16];
-    __shared__ __attribute__((aligned(16))) float ty[16][LT];
-    const WideIdx ix = wide_idx();
-    const int NB = (H + 15) / 16, HP = 16 * NB;
+constexpr int TNW_LT = GCN_WIDE_MAX_H + 16;        // row stride 16 mod 32: conflict-free ds_read_b32
+struct TnWideLds {
+    float tx[2][16][TNW_LT];
+    float ty[2][16][TNW_LT];
+};
+__global__ __launch_bounds__(512) void k_gemm_tn_w(int H, TnProblems pr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tnw_raw[];
+    TnWideLds& L = *reinterpret_cast<TnWideLds*>(tnw_raw);
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int NB = (H + 15) / 16, H4 = GCN_WIDE_MAX_H / 4;
     const int prob = blockIdx.z, slice = blockIdx.x, nslices = pr.nslices[prob];
     if (slice >= nslices) return;
-    const int nb = 4 * (int)blockIdx.y + ix.w;                 // this wavefront's block of dW rows
     const size_t rows = pr.rows[prob];
     const float* __restrict__ X = pr.X[prob];
     const float* __restrict__ Y = pr.Y[prob];
     const size_t ntiles = (rows + 15) / 16;
     const size_t per = (ntiles + nslices - 1) / nslices;
     const size_t t0 = (size_t)slice * per, t1 = min(ntiles, t0 + per);
-    f32x4 acc[WNB];
+    f32x4 acc[5][10];
 #pragma unroll
-    for (int k = 0; k < WNB; ++k) acc[k] = f4zero();
-    float bsum = 0.f;
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[i][k] = f4zero();
+    float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // staging: float4 number g of a chunk is (row g / 80, columns 4 (g % 80) ..); a thread owns g = t, t + 512, t + 1024
+    f32x4 xv[3], yv[3];
+    auto fetch = [&](size_t tile) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int g = t + 512 * u, r = g / H4, c = 4 * (g - r * H4);
+            const size_t row = tile * 16 + r;
+            const bool ok = g < 16 * H4 && row < rows && c < H;
+            xv[u] = ok ? ld4(X + row * H + c) : f4zero();
+            yv[u] = ok ? ld4(Y + row * H + c) : f4zero();
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int g = t + 512 * u, r = g / H4, c = 4 * (g - r * H4);
+            if (g < 16 * H4) { st4(&L.tx[buf][r][c], xv[u]); st4(&L.ty[buf][r][c], yv[u]); }
+        }
+    };
+    if (t0 < t1) { fetch(t0); stage(0); }
+    __syncthreads();
+    int buf = 0;
     for (size_t tile = t0; tile < t1; ++tile) {
-        const size_t row = tile * 16 + ix.arow;
-        {   // X columns 64 y .. 64 y + 63 of the tile, all Y columns
-            const int xcol = 64 * (int)blockIdx.y + 4 * ix.g0;
-            st4(&tx[ix.arow][4 * ix.g0], (row < rows && xcol < H) ? ld4(X + row * H + xcol) : f4zero());
-            for (int g = ix.g0; g < HP / 4; g += 16) {
-                const int acol = 4 * g;
-                st4(&ty[ix.arow][acol], (row < rows && acol < H) ? ld4(Y + row * H + acol) : f4zero());
+        if (tile + 1 < t1) fetch(tile + 1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float av[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                av[i] = L.tx[buf][4 * st + q][16 * (5 * wr + i) + rs];
+                bsum[i] += av[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                if (10 * wc + k < NB) {
+                    const float bv = L.ty[buf][4 * st + q][16 * (10 * wc + k) + rs];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if (5 * wr + i < NB) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][k], 0, 0, 0);
+                }
             }
         }
+        if (tile + 1 < t1) stage(buf ^ 1);
         __syncthreads();
-        if (nb < NB) {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const float av = tx[4 * st + ix.q][16 * ix.w + ix.rs];
-                bsum += av;
-#pragma unroll
-                for (int k = 0; k < WNB; ++k)
-                    if (k < NB) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ty[4 * st + ix.q][16 * k + ix.rs], acc[k], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+        buf ^= 1;
     }
-    if (nb >= NB) return;
     float* out = pr.out[prob] + (size_t)slice * pr.out_stride[prob];
 #pragma unroll
-    for (int k = 0; k < WNB; ++k)
+    for (int i = 0; i < 5; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int nn = 16 * nb + 4 * ix.q + r, kc = 16 * k + ix.rs;
-            if (k < NB && nn < H && kc < H) out[(size_t)nn * H + kc] = acc[k][r];
+        for (int k = 0; k < 10; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = 16 * (5 * wr + i) + 4 * q + r, kc = 16 * (10 * wc + k) + rs;
+                if (nn < H && kc < H) out[(size_t)nn * H + kc] = acc[i][k][r];
+            }
+    if (wc == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float bs = redq(bsum[i]);
+            const int n = 16 * (5 * wr + i) + rs;
+            if (q == 0 && n < H) out[(size_t)H * H + n] = bs;
         }
-    bsum = redq(bsum);
-    const int n = 16 * nb + ix.rs;
-    if (ix.q == 0 && n < H) out[(size_t)H * H + n] = bsum;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
