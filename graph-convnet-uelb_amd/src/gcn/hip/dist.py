@@ -32,17 +32,45 @@ def shard_batch(batch, rank_=None, world_=None):
     return {k: (v if k == "edge_cw" else v[lo:hi]) for k, v in batch.items()}
 
 
+def _staged(t):
+    """gloo cannot take device tensors on this stack (rehearsals of the multi-rank path on one GPU, tests): such
+    collectives go through a host copy.  The production backend is nccl (= RCCL), which reduces in place on the GPU."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def broadcast_(t, src=0, group=None):
+    if world() > 1:
+        if _staged(t):
+            c = t.detach().cpu()
+            dist.broadcast(c, src=src, group=group)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def allreduce_sum_(t, group=None):
+    if world() > 1:
+        if _staged(t):
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def broadcast_parameters(params, src=0):
     if world() > 1:
         for p in params:
-            dist.broadcast(p.data, src=src)
+            broadcast_(p.data, src=src)
 
 
 def allreduce_mean_(flat, group=None):
     """In-place mean over ranks of a flat tensor (the whole gradient in one message)."""
     w = world()
     if w > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        allreduce_sum_(flat, group)
         flat.mul_(1.0 / w)
     return flat
 

@@ -144,8 +144,7 @@ class Trainer:
         """n / (2 * count_k) over the whole global batch: label counts of the shards are summed over the ranks."""
         n1 = y_edges.sum().to(torch.float64)
         counts = torch.stack([y_edges.numel() - n1, n1])
-        if D.world() > 1:
-            torch.distributed.all_reduce(counts)
+        D.allreduce_sum_(counts)
         counts = counts.cpu()
         k = int((counts > 0).sum())
         w = torch.where(counts > 0, counts.sum() / (k * counts.clamp(min=1.0)), torch.ones(2, dtype=torch.float64))
