@@ -29,17 +29,24 @@ __device__ __forceinline__ WideIdx wide_idx() {
 }
 
 // Output columns 16 nb + 4 q .. + 3 of row rs of tile * W^T, W row-major [H][H] behind descriptor rW.
+// The weight rows come from L2 in groups of four 16-column blocks.  PIPE: two register sets alternate so that the
+// next group's loads are in flight during the current group's MFMAs (groups past the end use out-of-range offsets:
+// no memory traffic, zeros); worth its 16 registers only where the kernel's occupancy does not drop for it (the
+// backward kernels, already at one workgroup per CU: 7.5 -> 6.3 ms per layer at H = 300; the forward edge kernel
+// loses its second workgroup and gets slower).
+template <bool PIPE = false>
 __device__ __forceinline__ f32x4 wide_gemm(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q) {
     f32x4 acc0 = f4zero(), acc1 = f4zero();
     const int n = 16 * nb + rs;
     const uint32_t rowoff = n < H ? (uint32_t)n * (uint32_t)H * 4u : kOob;
-    for (int s0 = 0; s0 < NB; s0 += 4) {
-        f32x4 wf[4];
+    auto load = [&](f32x4 (&wf)[4], int s0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = 16 * (s0 + u) + 4 * q;
             wf[u] = bld4(rW, (s0 + u < NB && k < H && n < H) ? rowoff + (uint32_t)k * 4u : kOob);
         }
+    };
+    auto compute = [&](const f32x4 (&wf)[4], int s0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (s0 + u < NB) {
@@ -49,6 +56,22 @@ __device__ __forceinline__ f32x4 wide_gemm(const float (*tile)[WLS], rsrc_t rW, 
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in[2], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in[3], acc1, 0, 0, 0);
             }
+        }
+    };
+    f32x4 wa[4];
+    if constexpr (PIPE) {
+        f32x4 wb[4];
+        load(wa, 0);
+        for (int s0 = 0; s0 < NB; s0 += 8) {
+            load(wb, s0 + 4);
+            compute(wa, s0);
+            load(wa, s0 + 8);
+            compute(wb, s0 + 4);
+        }
+    } else {
+        for (int s0 = 0; s0 < NB; s0 += 4) {
+            load(wa, s0);
+            compute(wa, s0);
         }
     }
     return acc0 + acc1;
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_w(EdgeBwdArgs a) {
                     if (nb < NB) {
                         const int bcol = 16 * nb + 4 * ix.q;
                         const bool valid_b = jb < V && bcol < H;
-                        const f32x4 din = wide_gemm(tdet, rW, H, NB, nb, ix.rs, ix.q) + ld4(&tpre[ix.rs][bcol]);
+                        const f32x4 din = wide_gemm<true>(tdet, rW, H, NB, nb, ix.rs, ix.q) + ld4(&tpre[ix.rs][bcol]);
                         f32x4 rsum = ld4(&tdet[ix.rs][bcol]);
                         if (valid_b) {
                             st4(a.de + erow_b * H + bcol, din);
@@ -788,7 +811,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_w(
             const int bcol = 16 * nb + 4 * ix.q;
             h[k] = f4zero(); dmul[k] = f4zero();
             if (nb < NB) {
-                f32x4 pre = NHID ? wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q) : f4zero();
+                f32x4 pre = NHID ? wide_gemm<true>(tile, rW, H, NB, nb, ix.rs, ix.q) : f4zero();
                 if (bcol < H) {
                     if (NHID) {
                         pre += ld4(hp.hidB[0] + bcol);
@@ -860,7 +883,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_w(
             const int nb = ix.w + 4 * k;
             const int bcol = 16 * nb + 4 * ix.q;
             if (nb < NB) {
-                const f32x4 dv = NHID ? wide_gemm(tdp, rWt, H, NB, nb, ix.rs, ix.q) : ld4(&tdp[ix.rs][bcol]);
+                const f32x4 dv = NHID ? wide_gemm<true>(tdp, rWt, H, NB, nb, ix.rs, ix.q) : ld4(&tdp[ix.rs][bcol]);
                 if (rvalid && bcol < H) {
                     st4(de + row * H + bcol, dv);
                     if (do_next) {

@@ -49,6 +49,7 @@ class Trainer:
             raise ValueError(f"Unknown training strategy: {strategy_type}")
         self._fast = None
         self._packed = None
+        self._epochs_run = 0
         # steps that go through autograd (accumulation, REINFORCE) average their gradients over the ranks right
         # before the optimizer step; the graph-replay step reduces its flat gradient buffer itself
         self._sync_grads = False
@@ -66,7 +67,9 @@ class Trainer:
         if packed:
             dataset = self._packed_train_loader()
         else:
-            dataset = DatasetReader(cfg.get('num_train_data'), batch_size, "train", cfg)
+            # every rank reads the same global batches and takes its shard: the shuffle must be the same on all of them
+            dataset = DatasetReader(cfg.get('num_train_data'), batch_size, "train", cfg, seed=int(cfg.get('seed', 0)) + self._epochs_run)
+        self._epochs_run += 1
         self.strategy.reset_metrics()
         start = time.time()
         running_loss = running_err = 0.0
