@@ -138,23 +138,92 @@ __global__ __launch_bounds__(256) void k_node_fwd_w(NodeFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles.
-// partial layout [gridDim.x][4][H].
+// Two 16-row tiles (LDS rows 0..15 and 16..31) against the same weight rows: every group of weight rows fetched
+// from L2 feeds twice the MFMAs of wide_gemm.  two = false skips the second tile (wavefront-uniform).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_edge_fwd_w(EdgeFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+// x[0] <- x[1] <- ... <- x[WKB-1] <- x[0]: after WKB calls every entry is back in place
+__device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
+    const f32x4 t = x[0];
+#pragma unroll
+    for (int k = 0; k + 1 < WKB; ++k) x[k] = x[k + 1];
+    x[WKB - 1] = t;
+}
+
+template <bool PIPE>
+__device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, rsrc_t rW, int H, int NB, int nb, int rs, int q,
+                                           f32x4& o0, f32x4& o1) {
+    f32x4 a0 = f4zero(), b0 = f4zero(), a1 = f4zero(), b1 = f4zero();
+    const int n = 16 * nb + rs;
+    const uint32_t rowoff = n < H ? (uint32_t)n * (uint32_t)H * 4u : kOob;
+    auto load = [&](f32x4 (&wf)[4], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 16 * (s0 + u) + 4 * q;
+            wf[u] = bld4(rW, (s0 + u < NB && k < H && n < H) ? rowoff + (uint32_t)k * 4u : kOob);
+        }
+    };
+    auto compute = [&](const f32x4 (&wf)[4], int s0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u < NB) {
+                const f32x4 in0 = ld4(&tile[rs][16 * (s0 + u) + 4 * q]);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in0[0], a0, 0, 0, 0);
+                b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in0[1], b0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in0[2], a0, 0, 0, 0);
+                b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in0[3], b0, 0, 0, 0);
+                if (two) {
+                    const f32x4 in1 = ld4(&tile[16 + rs][16 * (s0 + u) + 4 * q]);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in1[0], a1, 0, 0, 0);
+                    b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in1[1], b1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in1[2], a1, 0, 0, 0);
+                    b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in1[3], b1, 0, 0, 0);
+                }
+            }
+        }
+    };
+    f32x4 wa[4];
+    if constexpr (PIPE) {
+        f32x4 wb[4];
+        load(wa, 0);
+        for (int s0 = 0; s0 < NB; s0 += 8) {
+            load(wb, s0 + 4);
+            compute(wa, s0);
+            load(wa, s0 + 8);
+            compute(wb, s0 + 4);
+        }
+    } else {
+        for (int s0 = 0; s0 < NB; s0 += 4) {
+            load(wa, s0);
+            compute(wa, s0);
+        }
+    }
+    o0 = a0 + b0;
+    o1 = a1 + b1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles two at a
+// time (32 rows in LDS per step).  partial layout [gridDim.x][4][H].
+// ------------------------------------------------------------------------------------------------
+#ifndef GCN_WIDE_PIPE_F
+#define GCN_WIDE_PIPE_F true
+#endif
+__global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[32][WLS];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
     const WideIdx ix = wide_idx();
     const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB;
     const EdgeSrc& S = a.src;
     clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&pxs[0][0])[k] = 0.f;
     const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
     const rsrc_t rW = make_rsrc(a.WU, (uint32_t)H * H * 4);
-    f32x4 s1[WKB], s2[WKB], px1[WKB], px2[WKB];
+    f32x4 s1[WKB], s2[WKB];
 #pragma unroll
-    for (int k = 0; k < WKB; ++k) { s1[k] = f4zero(); s2[k] = f4zero(); px1[k] = f4zero(); px2[k] = f4zero(); }
+    for (int k = 0; k < WKB; ++k) { s1[k] = f4zero(); s2[k] = f4zero(); }
     const int units = a.B * V * C;
     const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -165,54 +234,92 @@ __global__ __launch_bounds__(256) void k_edge_fwd_w(EdgeFwdArgs a) {
         f32x4 num[WKB], den[WKB];
 #pragma unroll
         for (int k = 0; k < WKB; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
-        for (int jt = 0; jt < njt; ++jt) {
-            {   // ---- phase A
-                const int j = jt * 16 + ix.arow;
+        for (int jt = 0; jt < njt; jt += 2) {
+            const bool two = jt + 1 < njt;
+            // ---- phase A: rows arow and 16 + arow of the step; all loads of a row are requested before the first is used
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s == 1 && !two) break;
+                const int j = (jt + s) * 16 + ix.arow;
+                const bool jok = j < V;
                 const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
-                const float capv = (S.mode == 2 && j < V) ? S.cap[(size_t)bi * V + j] : 0.f;
-                for (int g = ix.g0; g < HP / 4; g += 16) {
-                    const int acol = 4 * g;
-                    f32x4 val = f4zero();
-                    if (j < V && acol < H) {
-                        const size_t off = erow * H + acol;
-                        if (S.mode == 0) val = ld4(S.e_in + off);
-                        else if (S.mode == 2) val = ld4(&cl[CL_WE][acol]) * capv;
-                        else {
-                            val = bn_relu_res4(ld4(S.prev_tmp + off), ld4(S.prev_in + off), &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol],
-                                               &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
-                            if (dc.on) val *= drop_mul4(dc, drop_rowhash(dc, (uint32_t)erow), g);
-                        }
-                        if (S.mode != 0 && S.e_out != nullptr) st4(S.e_out + off, val);
+                float (*trow) = tile[16 * s + ix.arow];
+                if (S.mode == 1) {
+                    f32x4 pt[WKA], pi[WKA];
+#pragma unroll
+                    for (int k = 0; k < WKA; ++k) {
+                        const int acol = 4 * (ix.g0 + 16 * k);
+                        const size_t off = (jok && acol < H) ? erow * H + acol : 0;
+                        pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
                     }
-                    st4(&tile[ix.arow][acol], val);
+                    const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
+#pragma unroll
+                    for (int k = 0; k < WKA; ++k) {
+                        const int g = ix.g0 + 16 * k, acol = 4 * g;
+                        if (acol < HP) {
+                            f32x4 val = f4zero();
+                            if (jok && acol < H) {
+                                val = bn_relu_res4(pt[k], pi[k], &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol], &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
+                                if (dc.on) val *= drop_mul4(dc, rh, g);
+                                if (S.e_out != nullptr) st4(S.e_out + erow * H + acol, val);
+                            }
+                            st4(trow + acol, val);
+                        }
+                    }
+                } else {
+                    const float capv = (S.mode == 2 && jok) ? S.cap[(size_t)bi * V + j] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < WKA; ++k) {
+                        const int acol = 4 * (ix.g0 + 16 * k);
+                        if (acol < HP) {
+                            f32x4 val = f4zero();
+                            if (jok && acol < H) {
+                                const size_t off = erow * H + acol;
+                                if (S.mode == 0) val = ld4(S.e_in + off);
+                                else {
+                                    val = ld4(&cl[CL_WE][acol]) * capv;
+                                    if (S.e_out != nullptr) st4(S.e_out + off, val);
+                                }
+                            }
+                            st4(trow + acol, val);
+                        }
+                    }
                 }
             }
             __syncthreads();
-            {   // ---- phase B
-                const int j = jt * 16 + ix.rs;
-                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
-                const size_t nrow_j = (size_t)(b * V + min(j, V - 1)) * C + c;
-#pragma unroll
-                for (int k = 0; k < WKB; ++k) {
-                    const int nb = ix.w + 4 * k;
+            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
+#pragma unroll 1
+                for (int kk = 0; kk < WKB; ++kk) {
+                    constexpr int k = 0;
+                    const int nb = ix.w + 4 * kk;
                     if (nb < NB) {
                         const int bcol = 16 * nb + 4 * ix.q;
-                        const bool valid = j < V && bcol < H;
-                        f32x4 et = wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q);
-                        if (valid) {
-                            et += (ld4(a.Ve + (size_t)u * H + bcol) + ld4(a.bU + bcol)) + ld4(a.Ve + nrow_j * H + bcol);
-                            const f32x4 vnj = ld4(a.Vn + nrow_j * H + bcol);
-                            st4(a.e_tmp + erow * H + bcol, et);
+                        f32x4 et2[2];
+                        wide_gemm2<GCN_WIDE_PIPE_F>(tile, two, rW, H, NB, nb, ix.rs, ix.q, et2[0], et2[1]);
+                        if (bcol < H) {
+                            const f32x4 base = ld4(a.Ve + (size_t)u * H + bcol) + ld4(a.bU + bcol);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float g = sigmoidf_(et[r]);
-                                num[k][r] += g * vnj[r];
-                                den[k][r] += g;
-                                s1[k][r] += et[r];
-                                s2[k][r] += et[r] * et[r];
+                            for (int s = 0; s < 2; ++s) {
+                                const int j = (jt + s) * 16 + ix.rs;
+                                if (j < V) {
+                                    const size_t erow = ((size_t)bi * V + j) * C + c;
+                                    const size_t nrow_j = (size_t)(b * V + j) * C + c;
+                                    const f32x4 et = et2[s] + base + ld4(a.Ve + nrow_j * H + bcol);
+                                    const f32x4 vnj = ld4(a.Vn + nrow_j * H + bcol);
+                                    st4(a.e_tmp + erow * H + bcol, et);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float g = sigmoidf_(et[r]);
+                                        num[k][r] += g * vnj[r];
+                                        den[k][r] += g;
+                                        s1[k][r] += et[r];
+                                        s2[k][r] += et[r] * et[r];
+                                    }
+                                }
                             }
                         }
                     }
+                    rot(num); rot(den); rot(s1); rot(s2);
                 }
             }
             __syncthreads();
@@ -235,7 +342,9 @@ __global__ __launch_bounds__(256) void k_edge_fwd_w(EdgeFwdArgs a) {
                     st4(a.x_tmp + (size_t)u * H + bcol, xt);
                     st4(a.Aout + (size_t)u * H + bcol, A);
                     st4(a.Dout + (size_t)u * H + bcol, D);
-                    px1[k] += xt; px2[k] += xt * xt;
+                    // this lane is the only one that ever touches these four columns of pxs
+                    st4(&pxs[0][bcol], ld4(&pxs[0][bcol]) + xt);
+                    st4(&pxs[1][bcol], ld4(&pxs[1][bcol]) + xt * xt);
                 }
             }
         }
@@ -248,19 +357,25 @@ __global__ __launch_bounds__(256) void k_edge_fwd_w(EdgeFwdArgs a) {
             const f32x4 t1 = red16x4(s1[k]), t2 = red16x4(s2[k]);
             if (ix.rs == 0 && bcol < H) {
                 float* p = a.partial + (size_t)blockIdx.x * 4 * H;
-                st4(p + bcol, t1); st4(p + H + bcol, t2); st4(p + 2 * H + bcol, px1[k]); st4(p + 3 * H + bcol, px2[k]);
+                st4(p + bcol, t1); st4(p + H + bcol, t2); st4(p + 2 * H + bcol, ld4(&pxs[0][bcol])); st4(p + 3 * H + bcol, ld4(&pxs[1][bcol]));
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest.
+// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest; a unit walks its rows i two at
+// a time (LDS rows 0..15: the 16 columns j of row i, 16..31: those of row i + 1), so the column partial sums of a
+// thread cover both.  The residual-branch term dpre = de * dropout mask is re-read in phase B by the thread that
+// overwrites it instead of being staged through LDS, which leaves room for two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_edge_bwd_w(EdgeBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tdet[16][WLS];
-    __shared__ __attribute__((aligned(16))) float tpre[16][WLS];
+#ifndef GCN_WIDE_PIPE_B
+#define GCN_WIDE_PIPE_B true
+#endif
+__global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float tdet[32][WLS];
     __shared__ __attribute__((aligned(16))) float cc[16][GCN_WIDE_MAX_H];   // 0..5 edge BN, 6..11 node BN, 12..15 layer below
+    __shared__ __attribute__((aligned(16))) float qa[2][2][GCN_WIDE_MAX_H]; // per row of the step: qi, aggregate A
     const WideIdx ix = wide_idx();
     const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB;
     const bool do_next = a.next.tmp != nullptr;
@@ -294,43 +409,73 @@ __global__ __launch_bounds__(256) void k_edge_bwd_w(EdgeBwdArgs a) {
         const int it = tt % nit;
         const int b = tt / nit;
         const int ja = jt * 16 + ix.arow;
+        const bool jaok = ja < V;
         const size_t nrow_ja = (size_t)(b * V + min(ja, V - 1)) * C + c;
         f32x4 cve[WKA], cvn[WKA];
 #pragma unroll
         for (int k = 0; k < WKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
         const int i_end = min(V, (it + 1) * IT);
-        for (int i = it * IT; i < i_end; ++i) {
-            const size_t nrow_i = (size_t)(b * V + i) * C + c;
-            {   // ---- phase A
-                const size_t erow = ((size_t)(b * V + i) * V + min(ja, V - 1)) * C + c;
-                const uint32_t rhx = dcx.on ? drop_rowhash(dcx, (uint32_t)nrow_i) : 0u;
+        for (int i = it * IT; i < i_end; i += 2) {
+            const bool two = i + 1 < i_end;
+            // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
+            if (ix.t < 2 * (HP / 4)) {
+                const int s = ix.t >= HP / 4 ? 1 : 0, g = ix.t - s * (HP / 4), acol = 4 * g;
+                f32x4 qv = f4zero(), ai = f4zero();
+                if ((s == 0 || two) && acol < H) {
+                    const size_t nrow_i = (size_t)(b * V + i + s) * C + c;
+                    const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
+                    f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
+                    f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (dcx.on) dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), g);
+                    const f32x4 xmu = ld4(&cc[6][acol]), xrs = ld4(&cc[7][acol]), xga = ld4(&cc[8][acol]);
+                    const f32x4 xbe = ld4(&cc[9][acol]), xm1 = ld4(&cc[10][acol]), xm2 = ld4(&cc[11][acol]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xhx = (xt[r] - xmu[r]) * xrs[r];
+                        const float bnx = xhx * xga[r] + xbe[r];
+                        const float dxd = dxn[r] * dmx[r];
+                        const float dbnx = bnx > 0.f ? dxd : 0.f;
+                        const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
+                        qv[r] = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[r]) : dxt;
+                    }
+                }
+                st4(&qa[s][0][acol], qv);
+                st4(&qa[s][1][acol], ai);
+            }
+            __syncthreads();
+            // ---- phase A
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s == 1 && !two) break;
+                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
+                float* trow = tdet[16 * s + ix.arow];
+                // the two streams from memory first, all column groups at once
+                f32x4 dnv[WKA], tpv[WKA];
+#pragma unroll
+                for (int k = 0; k < WKA; ++k) {
+                    const int acol = 4 * (ix.g0 + 16 * k);
+                    const size_t off = (jaok && acol < H) ? erow * H + acol : 0;
+                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
+                }
                 const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
 #pragma unroll
                 for (int k = 0; k < WKA; ++k) {
                     const int g = ix.g0 + 16 * k;
                     const int acol = 4 * g;
                     if (acol < HP) {
-                        f32x4 det = f4zero(), dpre = f4zero();
-                        if (ja < V && acol < H) {
-                            const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
-                            f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f}, ai = f4zero();
-                            if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
-                            const f32x4 dn = ld4(a.de + erow * H + acol), tp = ld4(a.e_tmp + erow * H + acol);
+                        f32x4 det = f4zero();
+                        if (jaok && acol < H) {
+                            const f32x4 qv = ld4(&qa[s][0][acol]), ai = ld4(&qa[s][1][acol]);
+                            const f32x4 dn = dnv[k], tp = tpv[k];
                             const f32x4 vnj = ld4(a.Vn + nrow_ja * H + acol);
-                            f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f}, dme = f32x4{1.f, 1.f, 1.f, 1.f};
-                            if (dcx.on) { dmx = drop_mul4(dcx, rhx, g); dme = drop_mul4(dce, rhe, g); }
+                            f32x4 dme = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (dce.on) dme = drop_mul4(dce, rhe, g);
                             const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
                             const f32x4 ebe = ld4(&cc[3][acol]), em1 = ld4(&cc[4][acol]), em2 = ld4(&cc[5][acol]);
-                            const f32x4 xmu = ld4(&cc[6][acol]), xrs = ld4(&cc[7][acol]), xga = ld4(&cc[8][acol]);
-                            const f32x4 xbe = ld4(&cc[9][acol]), xm1 = ld4(&cc[10][acol]), xm2 = ld4(&cc[11][acol]);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float xhx = (xt[r] - xmu[r]) * xrs[r];
-                                const float bnx = xhx * xga[r] + xbe[r];
-                                const float dxd = dxn[r] * dmx[r];
-                                const float dbnx = bnx > 0.f ? dxd : 0.f;
-                                const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
-                                const float qi = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[r]) : dxt;
+                                const float qi = qv[r];
                                 const float x = tp[r];
                                 const float xh = (x - emu[r]) * ers[r];
                                 const float bn = xh * ega[r] + ebe[r];
@@ -339,55 +484,71 @@ __global__ __launch_bounds__(256) void k_edge_bwd_w(EdgeBwdArgs a) {
                                 const float gt = sigmoidf_(x);
                                 const float v = ega[r] * ers[r] * (dbn - em1[r] - xh * em2[r]) + qi * (vnj[r] - ai[r]) * gt * (1.f - gt);
                                 det[r] = v;
-                                dpre[r] = d;
                                 cve[k][r] += v;
                                 cvn[k][r] += qi * gt;
                             }
                             st4(a.det_out + erow * H + acol, det);
                         }
-                        st4(&tdet[ix.arow][acol], det);
-                        st4(&tpre[ix.arow][acol], dpre);
+                        st4(trow + acol, det);
                     }
                 }
             }
             __syncthreads();
-            {   // ---- phase B
+            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
                 const int jb = jt * 16 + ix.rs;
-                const size_t erow_b = ((size_t)(b * V + i) * V + min(jb, V - 1)) * C + c;
-                const uint32_t rhn = ndc.on ? drop_rowhash(ndc, (uint32_t)erow_b) : 0u;
-#pragma unroll
-                for (int k = 0; k < WKB; ++k) {
-                    const int nb = ix.w + 4 * k;
+                const bool jbok = jb < V;
+                const size_t erow_b0 = ((size_t)(b * V + i) * V + min(jb, V - 1)) * C + c;
+                const size_t nrow_i0 = (size_t)(b * V + i) * C + c;
+#pragma unroll 1
+                for (int kk = 0; kk < WKB; ++kk) {
+                    const int nb = ix.w + 4 * kk;
                     if (nb < NB) {
                         const int bcol = 16 * nb + 4 * ix.q;
-                        const bool valid_b = jb < V && bcol < H;
-                        const f32x4 din = wide_gemm<true>(tdet, rW, H, NB, nb, ix.rs, ix.q) + ld4(&tpre[ix.rs][bcol]);
-                        f32x4 rsum = ld4(&tdet[ix.rs][bcol]);
-                        if (valid_b) {
-                            st4(a.de + erow_b * H + bcol, din);
-                            if (do_next) {
-                                const f32x4 ntp = ld4(a.next.tmp + erow_b * H + bcol);
-                                const f32x4 nmu = ld4(&cc[12][bcol]), nrs = ld4(&cc[13][bcol]), nga = ld4(&cc[14][bcol]), nbe = ld4(&cc[15][bcol]);
-                                f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-                                if (ndc.on) dm = drop_mul4(ndc, rhn, bcol >> 2);
+                        const bool valid_b = jbok && bcol < H;
+                        // this thread's elements of de (read here, overwritten below) and of the next layer's pre-BN tensor
+                        f32x4 dold[2], ntp[2];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float xh = (ntp[r] - nmu[r]) * nrs[r];
-                                    const float bn = xh * nga[r] + nbe[r];
-                                    const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
-                                    na1[k][r] += d;
-                                    na2[k][r] += d * xh;
+                        for (int s = 0; s < 2; ++s) {
+                            const size_t off = (valid_b && (s == 0 || two)) ? (erow_b0 + (size_t)s * V * C) * H + bcol : 0;
+                            dold[s] = ld4(a.de + off);
+                            ntp[s] = do_next ? ld4(a.next.tmp + off) : f4zero();
+                        }
+                        f32x4 o2[2];
+                        wide_gemm2<GCN_WIDE_PIPE_B>(tdet, two, rW, H, NB, nb, ix.rs, ix.q, o2[0], o2[1]);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            if (s == 1 && !two) break;
+                            const size_t erow_b = erow_b0 + (size_t)s * V * C;
+                            f32x4 rsum = ld4(&tdet[16 * s + ix.rs][bcol]);
+                            if (valid_b) {
+                                f32x4 dpre = dold[s];
+                                if (dce.on) dpre *= drop_mul4(dce, drop_rowhash(dce, (uint32_t)erow_b), bcol >> 2);
+                                const f32x4 din = o2[s] + dpre;
+                                st4(a.de + erow_b * H + bcol, din);
+                                if (do_next) {
+                                    const f32x4 nmu = ld4(&cc[12][bcol]), nrs = ld4(&cc[13][bcol]), nga = ld4(&cc[14][bcol]), nbe = ld4(&cc[15][bcol]);
+                                    f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                                    if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)erow_b), bcol >> 2);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
+                                        const float bn = xh * nga[r] + nbe[r];
+                                        const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
+                                        na1[0][r] += d;
+                                        na2[0][r] += d * xh;
+                                    }
                                 }
                             }
+                            rsum = red16x4(rsum);
+                            if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i0 + (size_t)s * C) * H + bcol, rsum);
                         }
-                        rsum = red16x4(rsum);
-                        if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i) * H + bcol, rsum);
                     }
+                    rot(na1); rot(na2);
                 }
             }
             __syncthreads();
         }
-        if (ja < V) {
+        if (jaok) {
 #pragma unroll
             for (int k = 0; k < WKA; ++k) {
                 const int acol = 4 * (ix.g0 + 16 * k);

@@ -192,7 +192,7 @@ def test_layer_p0_train_equals_eval():
 
 # ---- hidden sizes above 64 (the kernels that stream the weights instead of holding them in registers)
 WIDE_LAYER_CASES = [(2, 5, 3, 80, "mean"), (1, 18, 2, 128, "mean"), (1, 6, 2, 300, "mean"), (2, 5, 2, 72, "sum"),
-                    (1, 17, 1, 320, "mean")]
+                    (1, 17, 1, 320, "mean"), (1, 40, 1, 80, "mean"), (1, 33, 2, 304, "sum")]
 
 
 @pytest.mark.parametrize("B,V,C,H,agg", WIDE_LAYER_CASES)
