@@ -149,9 +149,12 @@ __device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
     x[WKB - 1] = t;
 }
 
-template <bool PIPE>
-__device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, rsrc_t rW, int H, int NB, int nb, int rs, int q,
-                                           f32x4& o0, f32x4& o1) {
+// The k loop runs over groups of four 16-column blocks without a per-block test: the caller keeps the LDS columns
+// from 16 NB up to the next multiple of 64 at zero (wide_zero_pad), and weight blocks past NB load as zeros.  All LDS
+// operands of a group are requested before its first MFMA.
+template <bool PIPE, bool TWO>
+__device__ __forceinline__ void wide_gemm2t(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q,
+                                            f32x4& o0, f32x4& o1) {
     f32x4 a0 = f4zero(), b0 = f4zero(), a1 = f4zero(), b1 = f4zero();
     const int n = 16 * nb + rs;
     const uint32_t rowoff = n < H ? (uint32_t)n * (uint32_t)H * 4u : kOob;
@@ -163,21 +166,26 @@ __device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, r
         }
     };
     auto compute = [&](const f32x4 (&wf)[4], int s0) {
+        f32x4 in0[4], in1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (s0 + u < NB) {
-                const f32x4 in0 = ld4(&tile[rs][16 * (s0 + u) + 4 * q]);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in0[0], a0, 0, 0, 0);
-                b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in0[1], b0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in0[2], a0, 0, 0, 0);
-                b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in0[3], b0, 0, 0, 0);
-                if (two) {
-                    const f32x4 in1 = ld4(&tile[16 + rs][16 * (s0 + u) + 4 * q]);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in1[0], a1, 0, 0, 0);
-                    b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in1[1], b1, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in1[2], a1, 0, 0, 0);
-                    b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in1[3], b1, 0, 0, 0);
-                }
+            in0[u] = ld4(&tile[rs][16 * (s0 + u) + 4 * q]);
+            if constexpr (TWO) in1[u] = ld4(&tile[16 + rs][16 * (s0 + u) + 4 * q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs (the scheduler would sink each to its use)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in0[u][0], a0, 0, 0, 0);
+            b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in0[u][1], b0, 0, 0, 0);
+            if constexpr (TWO) {
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in1[u][0], a1, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in1[u][1], b1, 0, 0, 0);
+            }
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in0[u][2], a0, 0, 0, 0);
+            b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in0[u][3], b0, 0, 0, 0);
+            if constexpr (TWO) {
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in1[u][2], a1, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in1[u][3], b1, 0, 0, 0);
             }
         }
     };
@@ -187,9 +195,13 @@ __device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, r
         load(wa, 0);
         for (int s0 = 0; s0 < NB; s0 += 8) {
             load(wb, s0 + 4);
+            __builtin_amdgcn_sched_barrier(0);
             compute(wa, s0);
+            __builtin_amdgcn_sched_barrier(0);
             load(wa, s0 + 8);
-            compute(wb, s0 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 4 < NB) compute(wb, s0 + 4);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         for (int s0 = 0; s0 < NB; s0 += 4) {
@@ -199,6 +211,17 @@ __device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, r
     }
     o0 = a0 + b0;
     o1 = a1 + b1;
+}
+template <bool PIPE>
+__device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, rsrc_t rW, int H, int NB, int nb, int rs, int q,
+                                           f32x4& o0, f32x4& o1) {
+    if (two) wide_gemm2t<PIPE, true>(tile, rW, H, NB, nb, rs, q, o0, o1);
+    else wide_gemm2t<PIPE, false>(tile, rW, H, NB, nb, rs, q, o0, o1);
+}
+// zero columns 16 NB .. 16 ceil4(NB) - 1 of a 32-row LDS tile (never written afterwards)
+__device__ __forceinline__ void wide_zero_pad(float (*tile)[WLS], int NB, int t) {
+    const int c0 = 16 * NB, c1 = 16 * ((NB + 3) & ~3);
+    for (int e = t; e < 32 * (c1 - c0); e += 256) tile[e / (c1 - c0)][c0 + e % (c1 - c0)] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -219,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
     for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&pxs[0][0])[k] = 0.f;
+    wide_zero_pad(tile, NB, ix.t);
     const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
     const rsrc_t rW = make_rsrc(a.WU, (uint32_t)H * H * 4);
     f32x4 s1[WKB], s2[WKB];
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
 // overwrites it instead of being staged through LDS, which leaves room for two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_B
-#define GCN_WIDE_PIPE_B true
+#define GCN_WIDE_PIPE_B false
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float tdet[32][WLS];
@@ -392,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
     const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
     const rsrc_t rW = make_rsrc(a.WUt, (uint32_t)H * H * 4);
+    wide_zero_pad(tdet, NB, ix.t);
     f32x4 na1[WKB], na2[WKB];
 #pragma unroll
     for (int k = 0; k < WKB; ++k) { na1[k] = f4zero(); na2[k] = f4zero(); }
@@ -724,52 +749,89 @@ __global__ __launch_bounds__(512) void k_gemm_tn_w(int H, TnProblems pr) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) acc[i][k] = f4zero();
     float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    // staging: float4 number g of a chunk is (row g / 80, columns 4 (g % 80) ..); a thread owns g = t, t + 512, t + 1024
-    f32x4 xv[3], yv[3];
-    auto fetch = [&](size_t tile) {
+    // staging: float4 number g of a chunk is (row g / 80, columns 4 (g % 80) ..); a thread owns g = t, t + 512, t + 1024.
+    // Both operands are addressed through buffer descriptors that cover exactly this slice's rows (rows past the end
+    // and columns past H read as zeros).  The six float4 of the next chunk travel in three pairs, each fetched before
+    // one quarter of the chunk's MFMAs and stored to the other LDS buffer after it: 8 staging registers.
+    const size_t row0 = t0 * 16;
+    const uint32_t srows = t0 < t1 ? (uint32_t)min(rows - row0, (t1 - t0) * 16) : 0u;
+    const rsrc_t rX = make_rsrc(X + row0 * H, srows * (uint32_t)H * 4u), rY = make_rsrc(Y + row0 * H, srows * (uint32_t)H * 4u);
+    uint32_t voff[3];
+    int loff[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int g = t + 512 * u, r = g / H4, c = 4 * (g - r * H4);
-            const size_t row = tile * 16 + r;
-            const bool ok = g < 16 * H4 && row < rows && c < H;
-            xv[u] = ok ? ld4(X + row * H + c) : f4zero();
-            yv[u] = ok ? ld4(Y + row * H + c) : f4zero();
-        }
+    for (int u = 0; u < 3; ++u) {
+        const int g = t + 512 * u, r = g / H4, c = 4 * (g - r * H4);
+        voff[u] = (g < 16 * H4 && c < H) ? (uint32_t)(r * H + c) * 4u : kOob;
+        loff[u] = g < 16 * H4 ? r * TNW_LT + c : -1;
+    }
+    const uint32_t chunk_bytes = 16u * (uint32_t)H * 4u;
+    auto put = [&](float (*dst)[TNW_LT], int u, const f32x4 v) {
+        if (loff[u] >= 0) st4(&dst[0][0] + loff[u], v);
     };
-    auto stage = [&](int buf) {
+    // blocks of this wavefront that exist at this H (wavefront-uniform, kept in scalar registers)
+    const int ni = __builtin_amdgcn_readfirstlane(max(0, min(5, NB - 5 * wr)));
+    const int nk = __builtin_amdgcn_readfirstlane(max(0, min(10, NB - 10 * wc)));
+    // The chunk loop for a wavefront with NI x NK blocks; G: test every block against (ni, nk) at run time instead.
+    auto chunk_loop = [&](auto NI_, auto NK_, auto G_) {
+        constexpr int NI = decltype(NI_)::value, NK = decltype(NK_)::value;
+        constexpr bool G = decltype(G_)::value;
+        auto mfma_step = [&](int buf, int st) {
+            float av[NI];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int g = t + 512 * u, r = g / H4, c = 4 * (g - r * H4);
-            if (g < 16 * H4) { st4(&L.tx[buf][r][c], xv[u]); st4(&L.ty[buf][r][c], yv[u]); }
-        }
-    };
-    if (t0 < t1) { fetch(t0); stage(0); }
-    __syncthreads();
-    int buf = 0;
-    for (size_t tile = t0; tile < t1; ++tile) {
-        if (tile + 1 < t1) fetch(tile + 1);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            float av[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 av[i] = L.tx[buf][4 * st + q][16 * (5 * wr + i) + rs];
                 bsum[i] += av[i];
             }
+            if constexpr (G) {
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                if (10 * wc + k < NB) {
-                    const float bv = L.ty[buf][4 * st + q][16 * (10 * wc + k) + rs];
+                for (int k = 0; k < NK; ++k) {
+                    if (k < nk) {
+                        const float bv = L.ty[buf][4 * st + q][16 * (10 * wc + k) + rs];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (5 * wr + i < NB) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][k], 0, 0, 0);
+                        for (int i = 0; i < NI; ++i)
+                            if (i < ni) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][k], 0, 0, 0);
+                    }
+                }
+            } else {
+                // the Y operand of block k + 1 is requested before the MFMAs of block k; the scheduling barriers keep
+                // that order (left alone, the scheduler hoists every LDS read of the step and runs out of registers)
+                float bv = L.ty[buf][4 * st + q][16 * (10 * wc) + rs];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    float bn = 0.f;
+                    if (k + 1 < NK) bn = L.ty[buf][4 * st + q][16 * (10 * wc + k + 1) + rs];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][k], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bv = bn;
                 }
             }
+        };
+        int buf = 0;
+        for (size_t tile = t0; tile < t1; ++tile) {
+            const bool more = tile + 1 < t1;
+            const uint32_t nx = (uint32_t)(tile + 1 - t0) * chunk_bytes;
+            f32x4 s0 = f4zero(), s1 = f4zero();
+            if (more) { s0 = bld4(rX, voff[0] + nx); s1 = bld4(rX, voff[1] + nx); }
+            mfma_step(buf, 0);
+            if (more) { put(L.tx[buf ^ 1], 0, s0); put(L.tx[buf ^ 1], 1, s1); s0 = bld4(rX, voff[2] + nx); s1 = bld4(rY, voff[0] + nx); }
+            mfma_step(buf, 1);
+            if (more) { put(L.tx[buf ^ 1], 2, s0); put(L.ty[buf ^ 1], 0, s1); s0 = bld4(rY, voff[1] + nx); s1 = bld4(rY, voff[2] + nx); }
+            mfma_step(buf, 2);
+            if (more) { put(L.ty[buf ^ 1], 1, s0); put(L.ty[buf ^ 1], 2, s1); }
+            mfma_step(buf, 3);
+            __syncthreads();
+            buf ^= 1;
         }
-        if (tile + 1 < t1) stage(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
+    };
+    if (t0 < t1) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { put(L.tx[0], u, bld4(rX, voff[u])); put(L.ty[0], u, bld4(rY, voff[u])); }
     }
+    __syncthreads();
+    using std::integral_constant;
+    chunk_loop(integral_constant<int, 5>{}, integral_constant<int, 10>{}, integral_constant<bool, true>{});
     float* out = pr.out[prob] + (size_t)slice * pr.out_stride[prob];
 #pragma unroll
     for (int i = 0; i < 5; ++i)
