@@ -224,12 +224,32 @@ __device__ __forceinline__ void wide_zero_pad(float (*tile)[WLS], int NB, int t)
     for (int e = t; e < 32 * (c1 - c0); e += 256) tile[e / (c1 - c0)][c0 + e % (c1 - c0)] = 0.f;
 }
 
+// Two workgroups that start together on one CU stay in lockstep (both staging rows, then both competing for the
+// matrix pipe): the second half of the grid, which becomes the second resident of each CU, starts a fraction of a
+// step late so that one workgroup's memory phase runs under the other's MFMA phase.
+// phase stamps (GCN_PHASE_TRACE builds): the forward kernel writes the trace unless GCN_TRACE_BWD selects the backward one
+#ifdef GCN_TRACE_BWD
+#define GCN_STAMP_F(slot) do { } while (0)
+#define GCN_STAMP_B(slot) GCN_STAMP(slot)
+#else
+#define GCN_STAMP_F(slot) GCN_STAMP(slot)
+#define GCN_STAMP_B(slot) do { } while (0)
+#endif
+#ifndef GCN_WIDE_STAGGER
+#define GCN_WIDE_STAGGER 0
+#endif
+__device__ __forceinline__ void wide_stagger() {
+    if (GCN_WIDE_STAGGER > 0 && 2 * blockIdx.x >= gridDim.x) {
+        for (int k = 0; k < GCN_WIDE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles two at a
 // time (32 rows in LDS per step).  partial layout [gridDim.x][4][H].
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_F
-#define GCN_WIDE_PIPE_F true
+#define GCN_WIDE_PIPE_F false
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[32][WLS];
@@ -252,6 +272,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
     const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    wide_stagger();
+#ifdef GCN_PHASE_TRACE
+    int tstep = 0;
+#endif
     __syncthreads();
     for (int u = u0; u < u1; ++u) {
         const int bi = u / C, c = u - bi * C, b = bi / V;
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
         for (int k = 0; k < WKB; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
         for (int jt = 0; jt < njt; jt += 2) {
             const bool two = jt + 1 < njt;
+            GCN_STAMP_F(0);
             // ---- phase A: rows arow and 16 + arow of the step; all loads of a row are requested before the first is used
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -274,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                     for (int k = 0; k < WKA; ++k) {
                         const int acol = 4 * (ix.g0 + 16 * k);
                         const size_t off = (jok && acol < H) ? erow * H + acol : 0;
+#if defined(GCN_WIDE_PROBE) && GCN_WIDE_PROBE == 2
+                        pt[k] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)off; pi[k] = pt[k];
+#else
                         pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
+#endif
                     }
                     const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
 #pragma unroll
@@ -310,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                     }
                 }
             }
+            GCN_STAMP_F(1);
             __syncthreads();
+            GCN_STAMP_F(2);
             {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
 #pragma unroll 1
                 for (int kk = 0; kk < WKB; ++kk) {
@@ -318,18 +349,31 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                     const int nb = ix.w + 4 * kk;
                     if (nb < NB) {
                         const int bcol = 16 * nb + 4 * ix.q;
+                        // epilogue operands are requested before the product so that their latency hides under it
+                        const bool cok = bcol < H;
+                        f32x4 vej[2], vnj2[2];
+                        const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const int j = (jt + s) * 16 + ix.rs;
+                            const size_t off = (cok && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
+                            vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
+                        }
                         f32x4 et2[2];
+#if defined(GCN_WIDE_PROBE) && GCN_WIDE_PROBE == 1
+                        et2[0] = ld4(&tile[ix.rs][bcol]); et2[1] = ld4(&tile[16 + ix.rs][bcol]);
+#else
                         wide_gemm2<GCN_WIDE_PIPE_F>(tile, two, rW, H, NB, nb, ix.rs, ix.q, et2[0], et2[1]);
-                        if (bcol < H) {
-                            const f32x4 base = ld4(a.Ve + (size_t)u * H + bcol) + ld4(a.bU + bcol);
+#endif
+                        if (kk == 0) GCN_STAMP_F(3);
+                        if (cok) {
 #pragma unroll
                             for (int s = 0; s < 2; ++s) {
                                 const int j = (jt + s) * 16 + ix.rs;
                                 if (j < V) {
                                     const size_t erow = ((size_t)bi * V + j) * C + c;
-                                    const size_t nrow_j = (size_t)(b * V + j) * C + c;
-                                    const f32x4 et = et2[s] + base + ld4(a.Ve + nrow_j * H + bcol);
-                                    const f32x4 vnj = ld4(a.Vn + nrow_j * H + bcol);
+                                    const f32x4 et = et2[s] + base + vej[s];
+                                    const f32x4 vnj = vnj2[s];
                                     st4(a.e_tmp + erow * H + bcol, et);
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
@@ -343,10 +387,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                             }
                         }
                     }
+                    if (kk == 0) GCN_STAMP_F(4);
                     rot(num); rot(den); rot(s1); rot(s2);
                 }
             }
+            GCN_STAMP_F(5);
             __syncthreads();
+            GCN_STAMP_F(6);
+#ifdef GCN_PHASE_TRACE
+            ++tstep;
+#endif
         }
         // ---- unit end
 #pragma unroll
@@ -424,8 +474,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     const int nit = (V + IT - 1) / IT;
     const int units = a.B * nit * njt * C;
     const size_t Rn = (size_t)a.B * V * C;
-    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    // balanced ranges: every workgroup gets floor or ceil of units / gridDim.x
+    const int u0 = (int)((long long)blockIdx.x * units / (int)gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * units / (int)gridDim.x);
+    wide_stagger();
+#ifdef GCN_PHASE_TRACE
+    int tstep = 0;
+#endif
     __syncthreads();
     for (int u = u0; u < u1; ++u) {
         int tt = u;
@@ -442,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
         const int i_end = min(V, (it + 1) * IT);
         for (int i = it * IT; i < i_end; i += 2) {
             const bool two = i + 1 < i_end;
+            GCN_STAMP_B(0);
             // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
             if (ix.t < 2 * (HP / 4)) {
                 const int s = ix.t >= HP / 4 ? 1 : 0, g = ix.t - s * (HP / 4), acol = 4 * g;
@@ -469,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                 st4(&qa[s][1][acol], ai);
             }
             __syncthreads();
+            GCN_STAMP_B(1);
             // ---- phase A
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -518,7 +574,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                     }
                 }
             }
+            GCN_STAMP_B(2);
             __syncthreads();
+            GCN_STAMP_B(3);
             {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
                 const int jb = jt * 16 + ix.rs;
                 const bool jbok = jb < V;
@@ -540,6 +598,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                         }
                         f32x4 o2[2];
                         wide_gemm2<GCN_WIDE_PIPE_B>(tdet, two, rW, H, NB, nb, ix.rs, ix.q, o2[0], o2[1]);
+                        if (kk == 0) GCN_STAMP_B(4);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) {
                             if (s == 1 && !two) break;
@@ -571,7 +630,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                     rot(na1); rot(na2);
                 }
             }
+            GCN_STAMP_B(5);
             __syncthreads();
+            GCN_STAMP_B(6);
+#ifdef GCN_PHASE_TRACE
+            ++tstep;
+#endif
         }
         if (jaok) {
 #pragma unroll

@@ -20,13 +20,15 @@ from src.common.synthetic import CONFIGS, make_batch  # noqa: E402
 from src.gcn.hip import lib as L  # noqa: E402
 from src.gcn.hip.train_step import HipTrainStep  # noqa: E402
 
-shape = CONFIGS["nsfnet_10_commodities"]
+cfg_name = sys.argv[1] if len(sys.argv) > 1 else "nsfnet_10_commodities"
+shape = CONFIGS[cfg_name]
 dev = torch.device("cuda:0")
 model = build_model(shape, dev)
 b = make_batch(shape["B"], shape["V"], shape["C"], shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"], seed=1234)
 step = HipTrainStep(model, shape["B"], dev, use_graph=False)
+which = sys.argv[2] if len(sys.argv) > 2 else "fwd"      # wide configurations: build with -DGCN_TRACE_BWD for the backward kernel
 step.load_batch(b["edges_capacity"], b["commodities"][:, :, 2].astype(np.float32), b["nodes"], b["edges_target"], b["edge_cw"])
-for _ in range(5):
+for _ in range(2 if shape["H"] > 64 else 5):
     step.step()
 torch.cuda.synchronize()
 lib = L.load()
@@ -34,7 +36,9 @@ buf = (ctypes.c_ulonglong * 512)()
 lib.gcn_phase_trace_read.argtypes = [ctypes.c_void_p]
 assert lib.gcn_phase_trace_read(buf) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(64, 8)
-names = ["phaseA", "issue", "barrier", "lds+mfma", "epi-wait", "epilogue", "loop"]
+names = (["nodeside", "phaseA", "barrier", "product0", "blocks..", "barrier2", "next"] if which == "bwd" else
+         ["phaseA", "barrier", "product0", "epilogue0", "blocks1..", "barrier2", "next"] if shape["H"] > 64 else
+         ["phaseA", "issue", "barrier", "lds+mfma", "epi-wait", "epilogue", "loop"])
 print("step " + " ".join(f"{n:>9}" for n in names))
 for s in range(16):
     if t[s, 0] == 0:
