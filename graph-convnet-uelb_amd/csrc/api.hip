@@ -110,10 +110,10 @@ Dims make_dims(int B, int V, int C, int H) {
     d.IT = (int)std::max<long long>(1, std::min<long long>(V, fine / 1024));
     if (const char* e = getenv("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
-    // chunks of equal length (68 + 32 rows at V = 100 would leave half of the workgroups with twice the work); an even
-    // length, because the wide kernel walks the rows of a chunk in pairs
+    // chunks of equal length (68 + 32 rows at V = 100 would leave half of the workgroups with twice the work); a
+    // multiple of three where the wide kernel walks the rows of a chunk three at a time
     d.IT = (V + d.nit - 1) / d.nit;
-    if (H > 64 && (d.IT & 1) && d.IT < V) ++d.IT;
+    if (H > 64 && d.IT > 3) d.IT = std::min(V, (d.IT + 2) / 3 * 3);
     d.nit = (V + d.IT - 1) / d.IT;
     d.MT = (H + 15) / 16;
     return d;

@@ -138,9 +138,11 @@ __global__ __launch_bounds__(256) void k_node_fwd_w(NodeFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two 16-row tiles (LDS rows 0..15 and 16..31) against the same weight rows: every group of weight rows fetched
-// from L2 feeds twice the MFMAs of wide_gemm.  two = false skips the second tile (wavefront-uniform).
+// Up to WNS 16-row tiles (LDS rows 16 s .. 16 s + 15) against the same weight rows: every group of weight rows
+// fetched from L2 feeds WNS times the MFMAs of wide_gemm.  These kernels are bound by the L2 traffic of the
+// re-streamed weights (the whole H x H matrix per step of a workgroup), so rows per step is what sets their speed.
 // ------------------------------------------------------------------------------------------------
+constexpr int WNS = 3;
 // x[0] <- x[1] <- ... <- x[WKB-1] <- x[0]: after WKB calls every entry is back in place
 __device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
     const f32x4 t = x[0];
@@ -150,12 +152,14 @@ __device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
 }
 
 // The k loop runs over groups of four 16-column blocks without a per-block test: the caller keeps the LDS columns
-// from 16 NB up to the next multiple of 64 at zero (wide_zero_pad), and weight blocks past NB load as zeros.  All LDS
-// operands of a group are requested before its first MFMA.
-template <bool PIPE, bool TWO>
-__device__ __forceinline__ void wide_gemm2t(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q,
-                                            f32x4& o0, f32x4& o1) {
-    f32x4 a0 = f4zero(), b0 = f4zero(), a1 = f4zero(), b1 = f4zero();
+// from 16 NB up to the next multiple of 64 at zero (wide_zero_pad), and weight blocks past NB load as zeros.  The LDS
+// operands of half a group are requested before its first MFMA.
+template <bool PIPE, int NS>
+__device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q,
+                                             f32x4 (&o)[WNS]) {
+    f32x4 a[NS], b[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { a[s] = f4zero(); b[s] = f4zero(); }
     const int n = 16 * nb + rs;
     const uint32_t rowoff = n < H ? (uint32_t)n * (uint32_t)H * 4u : kOob;
     auto load = [&](f32x4 (&wf)[4], int s0) {
@@ -166,27 +170,28 @@ __device__ __forceinline__ void wide_gemm2t(const float (*tile)[WLS], rsrc_t rW,
         }
     };
     auto compute = [&](const f32x4 (&wf)[4], int s0) {
-        f32x4 in0[4], in1[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            in0[u] = ld4(&tile[rs][16 * (s0 + u) + 4 * q]);
-            if constexpr (TWO) in1[u] = ld4(&tile[16 + rs][16 * (s0 + u) + 4 * q]);
-        }
-        __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs (the scheduler would sink each to its use)
+        for (int h = 0; h < 2; ++h) {
+            f32x4 in[NS][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in0[u][0], a0, 0, 0, 0);
-            b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in0[u][1], b0, 0, 0, 0);
-            if constexpr (TWO) {
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][0], in1[u][0], a1, 0, 0, 0);
-                b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][1], in1[u][1], b1, 0, 0, 0);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) in[s][u] = ld4(&tile[16 * s + rs][16 * (s0 + 2 * h + u) + 4 * q]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads above the MFMAs (the scheduler would sink each to its use)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    a[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2 * h + u][0], in[s][u][0], a[s], 0, 0, 0);
+                    b[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2 * h + u][1], in[s][u][1], b[s], 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    a[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2 * h + u][2], in[s][u][2], a[s], 0, 0, 0);
+                    b[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2 * h + u][3], in[s][u][3], b[s], 0, 0, 0);
+                }
             }
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in0[u][2], a0, 0, 0, 0);
-            b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in0[u][3], b0, 0, 0, 0);
-            if constexpr (TWO) {
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][2], in1[u][2], a1, 0, 0, 0);
-                b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][3], in1[u][3], b1, 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     f32x4 wa[4];
@@ -197,11 +202,9 @@ __device__ __forceinline__ void wide_gemm2t(const float (*tile)[WLS], rsrc_t rW,
             load(wb, s0 + 4);
             __builtin_amdgcn_sched_barrier(0);
             compute(wa, s0);
-            __builtin_amdgcn_sched_barrier(0);
             load(wa, s0 + 8);
             __builtin_amdgcn_sched_barrier(0);
             if (s0 + 4 < NB) compute(wb, s0 + 4);
-            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         for (int s0 = 0; s0 < NB; s0 += 4) {
@@ -209,19 +212,30 @@ __device__ __forceinline__ void wide_gemm2t(const float (*tile)[WLS], rsrc_t rW,
             compute(wa, s0);
         }
     }
-    o0 = a0 + b0;
-    o1 = a1 + b1;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] = a[s] + b[s];
 }
+// ns (wavefront-uniform) = tiles in use, 1 .. WNS; o[s] for s >= ns is left untouched
 template <bool PIPE>
-__device__ __forceinline__ void wide_gemm2(const float (*tile)[WLS], bool two, rsrc_t rW, int H, int NB, int nb, int rs, int q,
-                                           f32x4& o0, f32x4& o1) {
-    if (two) wide_gemm2t<PIPE, true>(tile, rW, H, NB, nb, rs, q, o0, o1);
-    else wide_gemm2t<PIPE, false>(tile, rW, H, NB, nb, rs, q, o0, o1);
+__device__ __forceinline__ void wide_gemm_n(const float (*tile)[WLS], int ns, rsrc_t rW, int H, int NB, int nb, int rs, int q,
+                                            f32x4 (&o)[WNS]) {
+    if (ns >= 3) wide_gemm_ns<PIPE, 3>(tile, rW, H, NB, nb, rs, q, o);
+    else if (ns == 2) wide_gemm_ns<PIPE, 2>(tile, rW, H, NB, nb, rs, q, o);
+    else wide_gemm_ns<PIPE, 1>(tile, rW, H, NB, nb, rs, q, o);
 }
-// zero columns 16 NB .. 16 ceil4(NB) - 1 of a 32-row LDS tile (never written afterwards)
+// zero columns 16 NB .. 16 ceil4(NB) - 1 of a 16 WNS-row LDS tile (never written afterwards)
 __device__ __forceinline__ void wide_zero_pad(float (*tile)[WLS], int NB, int t) {
     const int c0 = 16 * NB, c1 = 16 * ((NB + 3) & ~3);
-    for (int e = t; e < 32 * (c1 - c0); e += 256) tile[e / (c1 - c0)][c0 + e % (c1 - c0)] = 0.f;
+    for (int e = t; e < 16 * WNS * (c1 - c0); e += 256) tile[e / (c1 - c0)][c0 + e % (c1 - c0)] = 0.f;
+}
+// sum over the 16 rows of a block of two per-lane partial sums, added by the one lane that owns the four columns into
+// per-workgroup LDS accumulators (same lane, same address every time: no atomics, fixed order)
+__device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int bcol, bool own, f32x4 t1, f32x4 t2) {
+    t1 = red16x4(t1); t2 = red16x4(t2);
+    if (own) {
+        st4(&acc[0][bcol], ld4(&acc[0][bcol]) + t1);
+        st4(&acc[1][bcol], ld4(&acc[1][bcol]) + t2);
+    }
 }
 
 // Two workgroups that start together on one CU stay in lockstep (both staging rows, then both competing for the
@@ -245,29 +259,27 @@ __device__ __forceinline__ void wide_stagger() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles two at a
-// time (32 rows in LDS per step).  partial layout [gridDim.x][4][H].
+// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles WNS at a
+// time (16 WNS rows in LDS per step).  partial layout [gridDim.x][4][H].
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_F
 #define GCN_WIDE_PIPE_F false
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[32][WLS];
+    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
     __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
+    __shared__ __attribute__((aligned(16))) float ess[2][GCN_WIDE_MAX_H];      // sums of e_tmp, e_tmp^2 over this workgroup's rows
     const WideIdx ix = wide_idx();
     const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB;
     const EdgeSrc& S = a.src;
     clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
-    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&pxs[0][0])[k] = 0.f;
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; }
     wide_zero_pad(tile, NB, ix.t);
     const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
     const rsrc_t rW = make_rsrc(a.WU, (uint32_t)H * H * 4);
-    f32x4 s1[WKB], s2[WKB];
-#pragma unroll
-    for (int k = 0; k < WKB; ++k) { s1[k] = f4zero(); s2[k] = f4zero(); }
     const int units = a.B * V * C;
     const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -282,13 +294,13 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
         f32x4 num[WKB], den[WKB];
 #pragma unroll
         for (int k = 0; k < WKB; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
-        for (int jt = 0; jt < njt; jt += 2) {
-            const bool two = jt + 1 < njt;
+        for (int jt = 0; jt < njt; jt += WNS) {
+            const int ns = min(WNS, njt - jt);
             GCN_STAMP_F(0);
             // ---- phase A: rows arow and 16 + arow of the step; all loads of a row are requested before the first is used
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s == 1 && !two) break;
+            for (int s = 0; s < WNS; ++s) {
+                if (s >= ns) break;
                 const int j = (jt + s) * 16 + ix.arow;
                 const bool jok = j < V;
                 const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
@@ -351,26 +363,28 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                         const int bcol = 16 * nb + 4 * ix.q;
                         // epilogue operands are requested before the product so that their latency hides under it
                         const bool cok = bcol < H;
-                        f32x4 vej[2], vnj2[2];
+                        f32x4 vej[WNS], vnj2[WNS];
                         const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
+                        for (int s = 0; s < WNS; ++s) {
                             const int j = (jt + s) * 16 + ix.rs;
-                            const size_t off = (cok && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
+                            const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
                             vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
                         }
-                        f32x4 et2[2];
+                        f32x4 et2[WNS];
 #if defined(GCN_WIDE_PROBE) && GCN_WIDE_PROBE == 1
-                        et2[0] = ld4(&tile[ix.rs][bcol]); et2[1] = ld4(&tile[16 + ix.rs][bcol]);
+#pragma unroll
+                        for (int s = 0; s < WNS; ++s) et2[s] = ld4(&tile[16 * s + ix.rs][bcol]);
 #else
-                        wide_gemm2<GCN_WIDE_PIPE_F>(tile, two, rW, H, NB, nb, ix.rs, ix.q, et2[0], et2[1]);
+                        wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2);
 #endif
                         if (kk == 0) GCN_STAMP_F(3);
+                        f32x4 t1 = f4zero(), t2 = f4zero();
                         if (cok) {
 #pragma unroll
-                            for (int s = 0; s < 2; ++s) {
+                            for (int s = 0; s < WNS; ++s) {
                                 const int j = (jt + s) * 16 + ix.rs;
-                                if (j < V) {
+                                if (s < ns && j < V) {
                                     const size_t erow = ((size_t)bi * V + j) * C + c;
                                     const f32x4 et = et2[s] + base + vej[s];
                                     const f32x4 vnj = vnj2[s];
@@ -380,15 +394,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                                         const float g = sigmoidf_(et[r]);
                                         num[k][r] += g * vnj[r];
                                         den[k][r] += g;
-                                        s1[k][r] += et[r];
-                                        s2[k][r] += et[r] * et[r];
+                                        t1[r] += et[r];
+                                        t2[r] += et[r] * et[r];
                                     }
                                 }
                             }
                         }
+                        wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
                     }
                     if (kk == 0) GCN_STAMP_F(4);
-                    rot(num); rot(den); rot(s1); rot(s2);
+                    rot(num); rot(den);
                 }
             }
             GCN_STAMP_F(5);
@@ -428,28 +443,29 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
         const int nb = ix.w + 4 * k;
         if (nb < NB) {
             const int bcol = 16 * nb + 4 * ix.q;
-            const f32x4 t1 = red16x4(s1[k]), t2 = red16x4(s2[k]);
-            if (ix.rs == 0 && bcol < H) {
+            if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
                 float* p = a.partial + (size_t)blockIdx.x * 4 * H;
-                st4(p + bcol, t1); st4(p + H + bcol, t2); st4(p + 2 * H + bcol, ld4(&pxs[0][bcol])); st4(p + 3 * H + bcol, ld4(&pxs[1][bcol]));
+                st4(p + bcol, ld4(&ess[0][bcol])); st4(p + H + bcol, ld4(&ess[1][bcol]));
+                st4(p + 2 * H + bcol, ld4(&pxs[0][bcol])); st4(p + 3 * H + bcol, ld4(&pxs[1][bcol]));
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest; a unit walks its rows i two at
-// a time (LDS rows 0..15: the 16 columns j of row i, 16..31: those of row i + 1), so the column partial sums of a
-// thread cover both.  The residual-branch term dpre = de * dropout mask is re-read in phase B by the thread that
+// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest; a unit walks its rows i WNS at
+// a time (LDS rows 16 s .. 16 s + 15: the 16 columns j of row i + s), so the column partial sums of a thread cover
+// all of them.  The residual-branch term dpre = de * dropout mask is re-read in phase B by the thread that
 // overwrites it instead of being staged through LDS, which leaves room for two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_B
 #define GCN_WIDE_PIPE_B false
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tdet[32][WLS];
-    __shared__ __attribute__((aligned(16))) float cc[16][GCN_WIDE_MAX_H];   // 0..5 edge BN, 6..11 node BN, 12..15 layer below
-    __shared__ __attribute__((aligned(16))) float qa[2][2][GCN_WIDE_MAX_H]; // per row of the step: qi, aggregate A
+    __shared__ __attribute__((aligned(16))) float tdet[16 * WNS][WLS];
+    __shared__ __attribute__((aligned(16))) float cc[6][GCN_WIDE_MAX_H];    // constants of the edge BatchNorm backward
+    __shared__ __attribute__((aligned(16))) float qa[WNS][2][GCN_WIDE_MAX_H]; // per row of the step: qi, aggregate A
+    __shared__ __attribute__((aligned(16))) float nss[2][GCN_WIDE_MAX_H];     // BN-backward sums of the layer below over this workgroup's rows
     const WideIdx ix = wide_idx();
     const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB;
     const bool do_next = a.next.tmp != nullptr;
@@ -457,19 +473,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     clds_fill(cc[0], a.stats, H, HP); clds_fill(cc[1], a.stats + H, H, HP);
     clds_fill(cc[2], a.gamma_e, H, HP); clds_fill(cc[3], a.beta_e, H, HP);
     clds_fill(cc[4], a.bstats_e, H, HP); clds_fill(cc[5], a.bstats_e + H, H, HP);
-    clds_fill(cc[6], a.stats + 2 * H, H, HP); clds_fill(cc[7], a.stats + 3 * H, H, HP);
-    clds_fill(cc[8], a.gamma_x, H, HP); clds_fill(cc[9], a.beta_x, H, HP);
-    clds_fill(cc[10], a.bstats_x, H, HP); clds_fill(cc[11], a.bstats_x + H, H, HP);
-    clds_fill(cc[12], do_next ? a.next.mean : nullptr, H, HP); clds_fill(cc[13], do_next ? a.next.rstd : nullptr, H, HP);
-    clds_fill(cc[14], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(cc[15], do_next ? a.next.beta : nullptr, H, HP);
     const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
     const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
     const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
     const rsrc_t rW = make_rsrc(a.WUt, (uint32_t)H * H * 4);
     wide_zero_pad(tdet, NB, ix.t);
-    f32x4 na1[WKB], na2[WKB];
-#pragma unroll
-    for (int k = 0; k < WKB; ++k) { na1[k] = f4zero(); na2[k] = f4zero(); }
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&nss[0][0])[k] = 0.f;
     const int njt = (V + 15) / 16;
     const int nit = (V + IT - 1) / IT;
     const int units = a.B * nit * njt * C;
@@ -494,22 +503,22 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < WKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
         const int i_end = min(V, (it + 1) * IT);
-        for (int i = it * IT; i < i_end; i += 2) {
-            const bool two = i + 1 < i_end;
+        for (int i = it * IT; i < i_end; i += WNS) {
+            const int ns = min(WNS, i_end - i);
             GCN_STAMP_B(0);
             // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
-            if (ix.t < 2 * (HP / 4)) {
-                const int s = ix.t >= HP / 4 ? 1 : 0, g = ix.t - s * (HP / 4), acol = 4 * g;
+            if (ix.t < WNS * (HP / 4)) {
+                const int s = ix.t / (HP / 4), g = ix.t - s * (HP / 4), acol = 4 * g;
                 f32x4 qv = f4zero(), ai = f4zero();
-                if ((s == 0 || two) && acol < H) {
+                if (s < ns && acol < H) {
                     const size_t nrow_i = (size_t)(b * V + i + s) * C + c;
                     const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
                     f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f};
                     if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
                     f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f};
                     if (dcx.on) dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), g);
-                    const f32x4 xmu = ld4(&cc[6][acol]), xrs = ld4(&cc[7][acol]), xga = ld4(&cc[8][acol]);
-                    const f32x4 xbe = ld4(&cc[9][acol]), xm1 = ld4(&cc[10][acol]), xm2 = ld4(&cc[11][acol]);
+                    const f32x4 xmu = ld4(a.stats + 2 * H + acol), xrs = ld4(a.stats + 3 * H + acol), xga = ld4(a.gamma_x + acol);
+                    const f32x4 xbe = ld4(a.beta_x + acol), xm1 = ld4(a.bstats_x + acol), xm2 = ld4(a.bstats_x + H + acol);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xhx = (xt[r] - xmu[r]) * xrs[r];
@@ -527,8 +536,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
             GCN_STAMP_B(1);
             // ---- phase A
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s == 1 && !two) break;
+            for (int s = 0; s < WNS; ++s) {
+                if (s >= ns) break;
                 const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
                 float* trow = tdet[16 * s + ix.arow];
                 // the two streams from memory first, all column groups at once
@@ -589,19 +598,25 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                         const int bcol = 16 * nb + 4 * ix.q;
                         const bool valid_b = jbok && bcol < H;
                         // this thread's elements of de (read here, overwritten below) and of the next layer's pre-BN tensor
-                        f32x4 dold[2], ntp[2];
+                        f32x4 dold[WNS], ntp[WNS];
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const size_t off = (valid_b && (s == 0 || two)) ? (erow_b0 + (size_t)s * V * C) * H + bcol : 0;
+                        for (int s = 0; s < WNS; ++s) {
+                            const size_t off = (valid_b && s < ns) ? (erow_b0 + (size_t)s * V * C) * H + bcol : 0;
                             dold[s] = ld4(a.de + off);
                             ntp[s] = do_next ? ld4(a.next.tmp + off) : f4zero();
                         }
-                        f32x4 o2[2];
-                        wide_gemm2<GCN_WIDE_PIPE_B>(tdet, two, rW, H, NB, nb, ix.rs, ix.q, o2[0], o2[1]);
+                        f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
+                        if (do_next) {
+                            const int cb = bcol < H ? bcol : 0;
+                            nmu = ld4(a.next.mean + cb); nrs = ld4(a.next.rstd + cb); nga = ld4(a.next.gamma + cb); nbe = ld4(a.next.beta + cb);
+                        }
+                        f32x4 o2[WNS];
+                        wide_gemm_n<GCN_WIDE_PIPE_B>(tdet, ns, rW, H, NB, nb, ix.rs, ix.q, o2);
                         if (kk == 0) GCN_STAMP_B(4);
+                        f32x4 t1 = f4zero(), t2 = f4zero();
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            if (s == 1 && !two) break;
+                        for (int s = 0; s < WNS; ++s) {
+                            if (s >= ns) break;
                             const size_t erow_b = erow_b0 + (size_t)s * V * C;
                             f32x4 rsum = ld4(&tdet[16 * s + ix.rs][bcol]);
                             if (valid_b) {
@@ -610,7 +625,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                                 const f32x4 din = o2[s] + dpre;
                                 st4(a.de + erow_b * H + bcol, din);
                                 if (do_next) {
-                                    const f32x4 nmu = ld4(&cc[12][bcol]), nrs = ld4(&cc[13][bcol]), nga = ld4(&cc[14][bcol]), nbe = ld4(&cc[15][bcol]);
                                     f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
                                     if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)erow_b), bcol >> 2);
 #pragma unroll
@@ -618,16 +632,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                                         const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
                                         const float bn = xh * nga[r] + nbe[r];
                                         const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
-                                        na1[0][r] += d;
-                                        na2[0][r] += d * xh;
+                                        t1[r] += d;
+                                        t2[r] += d * xh;
                                     }
                                 }
                             }
                             rsum = red16x4(rsum);
                             if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i0 + (size_t)s * C) * H + bcol, rsum);
                         }
+                        if (do_next) wide_acc_cols(nss, bcol, ix.rs == 0 && bcol < H, t1, t2);
                     }
-                    rot(na1); rot(na2);
                 }
             }
             GCN_STAMP_B(5);
@@ -654,10 +668,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
             const int nb = ix.w + 4 * k;
             if (nb < NB) {
                 const int bcol = 16 * nb + 4 * ix.q;
-                const f32x4 t1 = red16x4(na1[k]), t2 = red16x4(na2[k]);
-                if (ix.rs == 0 && bcol < H) {
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, t1);
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, t2);
+                if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nss[0][bcol]));
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nss[1][bcol]));
                 }
             }
         }

@@ -200,6 +200,15 @@ def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
     test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
 
 
+@pytest.mark.parametrize("it", [2, 3, 7, 40])
+@pytest.mark.parametrize("B,V,C,H,agg", [(1, 18, 2, 128, "mean"), (1, 40, 1, 80, "sum")])
+def test_wide_layer_row_chunks(monkeypatch, it, B, V, C, H, agg):
+    """The backward edge kernel walks the rows i of a chunk three at a time: chunk lengths that leave one, two or no
+    rows over, and one chunk for the whole graph (the library reads the chunk length override on every call)."""
+    monkeypatch.setenv("GCN_TUNE_IT", str(it))
+    test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
+
+
 @pytest.mark.parametrize("H,L,mlp_layers,voc", [(80, 2, 2, 2), (128, 3, 2, 2), (300, 2, 2, 2), (96, 2, 1, 2), (72, 2, 2, 1),
                                                  (16, 30, 2, 2), (32, 17, 3, 2),
                                                  # corner cases of the backward schedule: one or two layers, no hidden
