@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "graph-convnet-uelb_amd"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA: 256 CUs x 256 flop per cycle x 2.4 GHz
 DOMINANT_KERNEL = "k_edge_bwd3"        # k_edge_bwd_w at hidden sizes above 64
 
 
@@ -320,6 +321,14 @@ def main():
                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches_timed": int(n.value),
                     "whole_step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)}
+        if H > 64:
+            # above 64 channels the H x H product per edge row outweighs the row's bytes (2 H^2 flop against 12 H
+            # bytes: 50 flop per byte at H = 300, the fp32 MFMA / HBM balance point is about 20): matrix-pipe bound
+            algo_flops = 2.0 * H * H * Re
+            tflops = algo_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roofline.update({"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": algo_flops,
+                             "hbm_GBps": round(achieved, 1)})
         for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore
             p.grad = gview
 

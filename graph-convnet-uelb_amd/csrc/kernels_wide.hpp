@@ -4,8 +4,9 @@
 //   * phase B: wavefront w walks the 16-column blocks w, w + 4, ... of the output,
 //   * the H x H weights do not fit in registers or LDS: each 16-row tile streams the weight rows of its
 //     column block from memory (L2-resident) as MFMA A operands.
-// One LDS tile per operand (single buffered, two barriers per step).  These kernels favour coverage of
-// any H over speed; the math of each is stated above its argument block in kernels_fused.hpp.
+// One LDS tile per operand (single buffered, two barriers per step); the two edge kernels take up to three 16-row
+// tiles per step against one fetch of the weight rows (wide_gemm_ns).  The math of each kernel is stated above its
+// argument block in kernels_fused.hpp.
 #pragma once
 #include "common.hpp"
 #include "kernels_fused.hpp"
@@ -238,9 +239,6 @@ __device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int 
     }
 }
 
-// Two workgroups that start together on one CU stay in lockstep (both staging rows, then both competing for the
-// matrix pipe): the second half of the grid, which becomes the second resident of each CU, starts a fraction of a
-// step late so that one workgroup's memory phase runs under the other's MFMA phase.
 // phase stamps (GCN_PHASE_TRACE builds): the forward kernel writes the trace unless GCN_TRACE_BWD selects the backward one
 #ifdef GCN_TRACE_BWD
 #define GCN_STAMP_F(slot) do { } while (0)
@@ -249,15 +247,6 @@ __device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int 
 #define GCN_STAMP_F(slot) GCN_STAMP(slot)
 #define GCN_STAMP_B(slot) do { } while (0)
 #endif
-#ifndef GCN_WIDE_STAGGER
-#define GCN_WIDE_STAGGER 0
-#endif
-__device__ __forceinline__ void wide_stagger() {
-    if (GCN_WIDE_STAGGER > 0 && 2 * blockIdx.x >= gridDim.x) {
-        for (int k = 0; k < GCN_WIDE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles WNS at a
 // time (16 WNS rows in LDS per step).  partial layout [gridDim.x][4][H].
@@ -284,7 +273,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
     const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
-    wide_stagger();
 #ifdef GCN_PHASE_TRACE
     int tstep = 0;
 #endif
@@ -311,11 +299,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                     for (int k = 0; k < WKA; ++k) {
                         const int acol = 4 * (ix.g0 + 16 * k);
                         const size_t off = (jok && acol < H) ? erow * H + acol : 0;
-#if defined(GCN_WIDE_PROBE) && GCN_WIDE_PROBE == 2
-                        pt[k] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)off; pi[k] = pt[k];
-#else
                         pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
-#endif
                     }
                     const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
 #pragma unroll
@@ -372,12 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                             vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
                         }
                         f32x4 et2[WNS];
-#if defined(GCN_WIDE_PROBE) && GCN_WIDE_PROBE == 1
-#pragma unroll
-                        for (int s = 0; s < WNS; ++s) et2[s] = ld4(&tile[16 * s + ix.rs][bcol]);
-#else
                         wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2);
-#endif
                         if (kk == 0) GCN_STAMP_F(3);
                         f32x4 t1 = f4zero(), t2 = f4zero();
                         if (cok) {
@@ -485,7 +464,6 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     const size_t Rn = (size_t)a.B * V * C;
     // balanced ranges: every workgroup gets floor or ceil of units / gridDim.x
     const int u0 = (int)((long long)blockIdx.x * units / (int)gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * units / (int)gridDim.x);
-    wide_stagger();
 #ifdef GCN_PHASE_TRACE
     int tstep = 0;
 #endif
