@@ -209,6 +209,45 @@ def test_wide_layer_row_chunks(monkeypatch, it, B, V, C, H, agg):
     test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
 
 
+def test_wide_layer_many_steps_per_workgroup():
+    """H = 300 at 100 nodes x 6 commodities: 7 column tiles per (graph, row, commodity), row chunks of several
+    three-row steps, workgroups that own several units (the small cases above give every workgroup at most one step).
+    The oracle runs in float64 on the same device.  Among 18 million edge elements some BatchNorm outputs would sit
+    within float32 rounding of zero and flip their ReLU, which moves sum-type gradients by whole elements; the
+    BatchNorm biases are therefore set to +8 / -8 by channel (ReLU always open on two channels of three, always shut
+    on the third), which keeps every indexing path of the kernels in play and makes element-wise comparison valid."""
+    from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
+    dev = _dev()
+    torch.manual_seed(11)
+    B, V, C, H = 1, 100, 6, 300
+    layer = ResidualGatedGCNLayer(H, "mean")
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if "batch_norm.weight" in n:
+                p.add_(0.2 * torch.randn_like(p))
+            if "batch_norm.bias" in n:
+                p.copy_(torch.where(torch.arange(H) % 3 == 2, -8.0, 8.0))
+    layer = layer.to(dev).eval()
+    x = torch.randn(B, V, C, H, device=dev)
+    e = torch.randn(B, V, V, C, H, device=dev) * 3.0
+    gx = torch.randn(B, V, C, H, device=dev)
+    ge = torch.randn(B, V, V, C, H, device=dev)
+    P = {k: v.detach().double().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
+    x1, e1, _ = gcn_oracle.gcn_layer(xo, eo, P, "", "mean")
+    ((x1 * gx.double()).sum() + (e1 * ge.double()).sum()).backward()
+    xh, eh = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    x2, e2 = layer(xh, eh)
+    ((x2 * gx).sum() + (e2 * ge).sum()).backward()
+    assert_close(x2, x1, "x_new")
+    assert_close(e2, e1, "e_new")
+    assert_close(xh.grad, xo.grad, "dx_in")
+    assert_close(eh.grad, eo.grad, "de_in")
+    gmax = max(float(P[k].grad.abs().max()) for k in P)
+    for k, p in layer.named_parameters():
+        assert_close(p.grad, P[k].grad, "grad " + k, atol=1e-5 * gmax)
+
+
 @pytest.mark.parametrize("H,L,mlp_layers,voc", [(80, 2, 2, 2), (128, 3, 2, 2), (300, 2, 2, 2), (96, 2, 1, 2), (72, 2, 2, 1),
                                                  (16, 30, 2, 2), (32, 17, 3, 2),
                                                  # corner cases of the backward schedule: one or two layers, no hidden
