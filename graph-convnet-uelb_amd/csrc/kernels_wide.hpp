@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
         for (int jt = 0; jt < njt; jt += WNS) {
             const int ns = min(WNS, njt - jt);
             GCN_STAMP_F(0);
-            // ---- phase A: rows arow and 16 + arow of the step; all loads of a row are requested before the first is used
+            // ---- phase A: rows 16 s + arow of the step; all loads of a row are requested before the first is used
 #pragma unroll
             for (int s = 0; s < WNS; ++s) {
                 if (s >= ns) break;
@@ -484,6 +484,24 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
         for (int i = it * IT; i < i_end; i += WNS) {
             const int ns = min(WNS, i_end - i);
             GCN_STAMP_B(0);
+            // Requested before anything else of the step: the Vn row of column j (it serves every row i of the step) and
+            // the two streams of the first row; the streams of the later rows follow when their turn comes.
+            f32x4 vnv[WKA], dnv[WKA], tpv[WKA];
+            auto load_streams = [&](int s) {
+                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
+#pragma unroll
+                for (int k = 0; k < WKA; ++k) {
+                    const int acol = 4 * (ix.g0 + 16 * k);
+                    const size_t off = (jaok && acol < H) ? erow * H + acol : 0;
+                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < WKA; ++k) {
+                const int acol = 4 * (ix.g0 + 16 * k);
+                vnv[k] = ld4(a.Vn + ((jaok && acol < H) ? nrow_ja * H + acol : 0));
+            }
+            load_streams(0);
             // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
             if (ix.t < WNS * (HP / 4)) {
                 const int s = ix.t / (HP / 4), g = ix.t - s * (HP / 4), acol = 4 * g;
@@ -518,14 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                 if (s >= ns) break;
                 const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
                 float* trow = tdet[16 * s + ix.arow];
-                // the two streams from memory first, all column groups at once
-                f32x4 dnv[WKA], tpv[WKA];
-#pragma unroll
-                for (int k = 0; k < WKA; ++k) {
-                    const int acol = 4 * (ix.g0 + 16 * k);
-                    const size_t off = (jaok && acol < H) ? erow * H + acol : 0;
-                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
-                }
+                if (s > 0) load_streams(s);
                 const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
 #pragma unroll
                 for (int k = 0; k < WKA; ++k) {
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                         if (jaok && acol < H) {
                             const f32x4 qv = ld4(&qa[s][0][acol]), ai = ld4(&qa[s][1][acol]);
                             const f32x4 dn = dnv[k], tp = tpv[k];
-                            const f32x4 vnj = ld4(a.Vn + nrow_ja * H + acol);
+                            const f32x4 vnj = vnv[k];
                             f32x4 dme = f32x4{1.f, 1.f, 1.f, 1.f};
                             if (dce.on) dme = drop_mul4(dce, rhe, g);
                             const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
