@@ -131,15 +131,19 @@ def test_model_matches_reference_golden(path):
         assert_close(p.grad, g["grad." + k], "grad " + k, atol=1e-6 * gmax)
 
 
-def test_layer_train_mode_dropout_semantics():
+@pytest.mark.parametrize("B,V,C,H,it", [(3, 14, 4, 64, 0), (1, 35, 2, 96, 4), (1, 20, 2, 304, 20)])
+def test_layer_train_mode_dropout_semantics(monkeypatch, B, V, C, H, it):
     """Train-mode outputs cannot match the reference bit for bit (different RNG).  Check instead that
     (1) ~(1-p) of the elements survive, (2) the output equals the oracle's pre-dropout output times
     mask/(1-p) with the mask read off the HIP output, i.e. dropout acts on relu(BN)+residual as in
     gcn_layers.py:124-128, (3) backward regenerates the same mask (gradients equal the oracle's with that
-    mask), (4) the mask changes from call to call, and eval mode is deterministic."""
+    mask), (4) the mask changes from call to call, and eval mode is deterministic.  The cases above 64 channels walk
+    several column tiles and several rows per step (it = row-chunk length override, 0 = the library's choice)."""
     from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
     dev = _dev()
-    B, V, C, H, p = 3, 14, 4, 64, 0.3
+    if it:
+        monkeypatch.setenv("GCN_TUNE_IT", str(it))
+    p = 0.3
     for seed in range(64):
         torch.manual_seed(seed)
         layer = ResidualGatedGCNLayer(H, "mean", dropout_rate=p)
@@ -156,7 +160,7 @@ def test_layer_train_mode_dropout_semantics():
     x1, e1 = layer(xh, eh)
     ((x1 * gx.to(dev)).sum() + (e1 * ge.to(dev)).sum()).backward()
     mx, me = (x1 != 0).float().cpu(), (e1 != 0).float().cpu()
-    assert abs(me.mean().item() - (1 - p)) < 0.01 and abs(mx.mean().item() - (1 - p)) < 0.03
+    assert abs(me.mean().item() - (1 - p)) < 0.01 and abs(mx.mean().item() - (1 - p)) < 0.04
     xo, eo = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
     xp, ep, _ = gcn_oracle.gcn_layer(xo, eo, P, "", "mean")
     assert float(xp.detach().abs().min()) > 0 and float(ep.detach().abs().min()) > 0
