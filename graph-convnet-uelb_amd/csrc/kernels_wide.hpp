@@ -155,7 +155,7 @@ __device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
 // The k loop runs over groups of four 16-column blocks without a per-block test: the caller keeps the LDS columns
 // from 16 NB up to the next multiple of 64 at zero (wide_zero_pad), and weight blocks past NB load as zeros.  The LDS
 // operands of half a group are requested before its first MFMA.
-template <bool PIPE, int NS>
+template <int PIPE, int NS>
 __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q,
                                              f32x4 (&o)[WNS]) {
     f32x4 a[NS], b[NS];
@@ -196,7 +196,22 @@ __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW
         }
     };
     f32x4 wa[4];
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 2) {              // weight groups requested two groups ahead of their MFMAs
+        f32x4 wb[4], wc[4];
+        load(wa, 0);
+        load(wb, 4);
+        for (int s0 = 0; s0 < NB; s0 += 12) {
+            load(wc, s0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(wa, s0);
+            load(wa, s0 + 12);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 4 < NB) compute(wb, s0 + 4);
+            load(wb, s0 + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 8 < NB) compute(wc, s0 + 8);
+        }
+    } else if constexpr (PIPE == 1) {       // one group ahead
         f32x4 wb[4];
         load(wa, 0);
         for (int s0 = 0; s0 < NB; s0 += 8) {
@@ -217,7 +232,7 @@ __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW
     for (int s = 0; s < NS; ++s) o[s] = a[s] + b[s];
 }
 // ns (wavefront-uniform) = tiles in use, 1 .. WNS; o[s] for s >= ns is left untouched
-template <bool PIPE>
+template <int PIPE>
 __device__ __forceinline__ void wide_gemm_n(const float (*tile)[WLS], int ns, rsrc_t rW, int H, int NB, int nb, int rs, int q,
                                             f32x4 (&o)[WNS]) {
     if (ns >= 3) wide_gemm_ns<PIPE, 3>(tile, rW, H, NB, nb, rs, q, o);
@@ -252,7 +267,7 @@ __device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int 
 // time (16 WNS rows in LDS per step).  partial layout [gridDim.x][4][H].
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_F
-#define GCN_WIDE_PIPE_F false
+#define GCN_WIDE_PIPE_F 0
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
 // overwrites it instead of being staged through LDS, which leaves room for two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 #ifndef GCN_WIDE_PIPE_B
-#define GCN_WIDE_PIPE_B false
+#define GCN_WIDE_PIPE_B 0
 #endif
 __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float tdet[16 * WNS][WLS];
