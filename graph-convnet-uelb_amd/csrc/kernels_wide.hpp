@@ -15,7 +15,7 @@
 
 constexpr int GCN_WIDE_MAX_H = 320;
 constexpr int WNB = GCN_WIDE_MAX_H / 16;       // column blocks
-constexpr int WLS = GCN_WIDE_MAX_H + 4;        // LDS row stride (floats)
+constexpr int WLS = GCN_WIDE_MAX_H + 8;        // LDS row stride (floats), 8 mod 64: the 128-bit MFMA operand reads of lane (rs, q) at row rs, column 4 q fall on 16 different bank quads in every 16-lane group of ds_read_b128 (4 mod 64 is two-way conflicted)
 constexpr int WKA = GCN_WIDE_MAX_H / 64;       // column groups per phase-A thread
 constexpr int WKB = (WNB + 3) / 4;             // column blocks per wavefront
 
