@@ -935,25 +935,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn_w(int H, TnProblems pr) {
 
 // ------------------------------------------------------------------------------------------------
 // Head (edge MLP with at most one hidden layer, loss, edge error), forward.  Same outputs as k_head_fwd;
-// loss_partial has one row per workgroup.
+// loss_partial has one row per workgroup.  Steps of up to WNS 16-row tiles, as in the edge kernels.
 // ------------------------------------------------------------------------------------------------
-struct HeadRowLogits {
-    float l0, l1;
-};
-// Sum over the workgroup of per-lane partial dot products of one row (lane (rs, q) of every wavefront holds a part
-// of row rs): returns the totals of row rs to every lane.  red: [4 waves][16 rows][2].
-__device__ __forceinline__ HeadRowLogits head_row_sum(float p0, float p1, float (*red)[16][2], const WideIdx& ix) {
-    p0 = redq(p0); p1 = redq(p1);
-    if (ix.q == 0) { red[ix.w][ix.rs][0] = p0; red[ix.w][ix.rs][1] = p1; }
-    __syncthreads();
-    HeadRowLogits o;
-    o.l0 = red[0][ix.rs][0] + red[1][ix.rs][0] + red[2][ix.rs][0] + red[3][ix.rs][0];
-    o.l1 = red[0][ix.rs][1] + red[1][ix.rs][1] + red[2][ix.rs][1] + red[3][ix.rs][1];
-    __syncthreads();
-    return o;
-}
-
-// phase A of both head kernels: the head's input tile from EdgeSrc into LDS (and optionally to e_stash)
+// phase A of both head kernels: 16 rows of the head's input from EdgeSrc into LDS (and optionally to e_stash)
 __device__ __forceinline__ void head_src_tile(float (*tile)[WLS], const EdgeSrc& S, const float (*cl)[GCN_WIDE_MAX_H],
                                               const DropCfg& dc, size_t tile0, size_t rows, int H, int HP, int C,
                                               float* e_stash, const WideIdx& ix) {
@@ -976,78 +960,116 @@ __device__ __forceinline__ void head_src_tile(float (*tile)[WLS], const EdgeSrc&
         st4(&tile[ix.arow][acol], val);
     }
 }
+// Per row of up to WNS tiles: the two logits from per-lane partial dot products (lane (rs, q) of every wavefront holds
+// a part of row rs of each tile).  Two barriers; after the second, no wavefront still reads what the partials came from.
+__device__ __forceinline__ void head_row_sums(float (&p0)[WNS], float (&p1)[WNS], float (*red)[4][16][2], const WideIdx& ix) {
+#pragma unroll
+    for (int s = 0; s < WNS; ++s) {
+        const float a = redq(p0[s]), b = redq(p1[s]);
+        if (ix.q == 0) { red[s][ix.w][ix.rs][0] = a; red[s][ix.w][ix.rs][1] = b; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < WNS; ++s) {
+        p0[s] = red[s][0][ix.rs][0] + red[s][1][ix.rs][0] + red[s][2][ix.rs][0] + red[s][3][ix.rs][0];
+        p1[s] = red[s][0][ix.rs][1] + red[s][1][ix.rs][1] + red[s][2][ix.rs][1] + red[s][3][ix.rs][1];
+    }
+    __syncthreads();
+}
 
 template <int NHID>
-__global__ __launch_bounds__(256) void k_head_fwd_w(
+__global__ __launch_bounds__(256, 2) void k_head_fwd_w(
     size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, const float* __restrict__ cap, int mask_invalid,
     const long long* __restrict__ y_edges, const float* __restrict__ edge_cw, float* __restrict__ logits,
     float* __restrict__ loss_partial, int* __restrict__ counts, const unsigned long long* __restrict__ rng, int stream_id0,
     float p, int training) {
     static_assert(NHID <= 1, "the wide head supports at most one hidden layer");
-    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
+    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
-    __shared__ float red[4][16][2];
+    __shared__ float red[WNS][4][16][2];
     const WideIdx ix = wide_idx();
     const int NB = (H + 15) / 16, HP = 16 * NB;
     clds_fill(cl[CL_PMEAN], src.mode == 1 ? src.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], src.mode == 1 ? src.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], src.mode == 1 ? src.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], src.mode == 1 ? src.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], src.mode == 2 ? src.we : nullptr, H, HP);
+    wide_zero_pad(tile, NB, ix.t);
     const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
     const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
     const rsrc_t rW = make_rsrc(NHID ? hp.hidW[0] : hp.outW, (uint32_t)H * H * 4);
-    const size_t ntiles = (rows + 15) / 16;
+    const size_t ntiles = (rows + 15) / 16, nsteps = (ntiles + WNS - 1) / WNS;
     const int BC_stride = V * V * C;
     const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
     const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
     float acc_wn = 0.f, acc_w = 0.f;
     __syncthreads();
-    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        head_src_tile(tile, src, cl, sdc, tl * 16, rows, H, HP, C, nullptr, ix);
+    for (size_t stp = blockIdx.x; stp < nsteps; stp += gridDim.x) {
+        const int ns = (int)min((size_t)WNS, ntiles - stp * WNS);
+#pragma unroll
+        for (int s = 0; s < WNS; ++s)
+            if (s < ns) head_src_tile(tile + 16 * s, src, cl, sdc, (stp * WNS + s) * 16, rows, H, HP, C, nullptr, ix);
         __syncthreads();
-        const size_t row = tl * 16 + ix.rs;
-        const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
-        float p0 = 0.f, p1 = 0.f;
+        float p0[WNS], p1[WNS];
 #pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            const int bcol = 16 * nb + 4 * ix.q;
+        for (int s = 0; s < WNS; ++s) { p0[s] = 0.f; p1[s] = 0.f; }
+#pragma unroll 1
+        for (int kk = 0; kk < WKB; ++kk) {
+            const int nb = ix.w + 4 * kk;
             if (nb < NB) {                                   // wavefront-uniform: every lane takes part in the MFMAs
-                f32x4 h = NHID ? wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q) : ld4(&tile[ix.rs][bcol]);
-                if (bcol < H) {
-                    if (NHID) {
-                        h += ld4(hp.hidB[0] + bcol);
+                const int bcol = 16 * nb + 4 * ix.q;
+                const bool cok = bcol < H;
+                f32x4 h[WNS];
+                if (NHID) {
+                    wide_gemm_n<0>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, h);
+                } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h[r] = h[r] > 0.f ? h[r] : 0.f;
-                        if (hdc.on) h *= drop_mul4(hdc, rh, bcol >> 2);
-                    }
+                    for (int s = 0; s < WNS; ++s) h[s] = ld4(&tile[16 * s + ix.rs][bcol]);
+                }
+                if (cok) {
                     const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
+                    const f32x4 hb = NHID ? ld4(hp.hidB[0] + bcol) : f4zero();
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { p0 += h[r] * w0[r]; p1 += h[r] * w1[r]; }
+                    for (int s = 0; s < WNS; ++s) {
+                        if (s < ns) {
+                            f32x4 hv = h[s];
+                            if (NHID) {
+                                hv += hb;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) hv[r] = hv[r] > 0.f ? hv[r] : 0.f;
+                                if (hdc.on) hv *= drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)((stp * WNS + s) * 16 + ix.rs)), bcol >> 2);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { p0[s] += hv[r] * w0[r]; p1[s] += hv[r] * w1[r]; }
+                        }
+                    }
                 }
             }
         }
-        const HeadRowLogits lg = head_row_sum(p0, p1, red, ix);
-        float l0 = lg.l0 + b2_0, l1 = lg.l1 + b2_1;
-        if (row < rows && ix.w == 0 && ix.q == 0) {
-            if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
-            if (voc == 1) {
-                logits[row] = l0;
-            } else {
-                logits[row * 2] = l0;
-                logits[row * 2 + 1] = l1;
-                if (y_edges != nullptr) {
-                    const int y = (int)y_edges[row];
-                    const float mx = fmaxf(l0, l1);
-                    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
-                    const float w = y ? cw1 : cw0;
-                    acc_wn += -w * ((y ? l1 : l0) - lse);
-                    acc_w += w;
-                    const int pred = l1 > l0 ? 1 : 0;
-                    if (y + pred > 0) {
-                        const int b = (int)(row / BC_stride), c = (int)(row % C);
-                        const int BC = (int)(rows / BC_stride) * C;
-                        atomicAdd(&counts[BC + b * C + c], 1);
-                        if (pred == y) atomicAdd(&counts[b * C + c], 1);
+        head_row_sums(p0, p1, red, ix);
+#pragma unroll
+        for (int s = 0; s < WNS; ++s) {
+            const size_t row = (stp * WNS + s) * 16 + ix.rs;
+            float l0 = p0[s] + b2_0, l1 = p1[s] + b2_1;
+            if (s < ns && row < rows && ix.w == 0 && ix.q == 0) {
+                if (mask_invalid && cap[row / C] == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+                if (voc == 1) {
+                    logits[row] = l0;
+                } else {
+                    logits[row * 2] = l0;
+                    logits[row * 2 + 1] = l1;
+                    if (y_edges != nullptr) {
+                        const int y = (int)y_edges[row];
+                        const float mx = fmaxf(l0, l1);
+                        const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+                        const float w = y ? cw1 : cw0;
+                        acc_wn += -w * ((y ? l1 : l0) - lse);
+                        acc_w += w;
+                        const int pred = l1 > l0 ? 1 : 0;
+                        if (y + pred > 0) {
+                            const int b = (int)(row / BC_stride), c = (int)(row % C);
+                            const int BC = (int)(rows / BC_stride) * C;
+                            atomicAdd(&counts[BC + b * C + c], 1);
+                            if (pred == y) atomicAdd(&counts[b * C + c], 1);
+                        }
                     }
                 }
             }
@@ -1067,145 +1089,198 @@ __global__ __launch_bounds__(256) void k_head_fwd_w(
 // Head backward (same outputs as k_head_bwd, NHID <= 1).  wpartial has one row per workgroup:
 // [voc][H] output-layer weight gradient followed by voc bias gradients, row stride (voc*H + voc + 3) & ~3.
 // hidWt: the transposed hidden weight (needed only with NHID = 1).
+// Per step of up to WNS tiles: input rows to LDS; first product -> hidden pre-activations (kept in registers, 60 per
+// lane); logits -> d logits; dpre written over the input rows in LDS (every wavefront is past the first product by
+// then); second product -> de and the BatchNorm-backward sums of the last conv layer.  Per-channel sums in LDS.
 // ------------------------------------------------------------------------------------------------
 template <int NHID>
-__global__ __launch_bounds__(256) void k_head_bwd_w(
+__global__ __launch_bounds__(256, 2) void k_head_bwd_w(
     size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ hidWt, EdgeSrc src, NextBn next,
     float* __restrict__ e_stash, const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
     const float* __restrict__ edge_cw, const float* __restrict__ loss_out, const float* __restrict__ dloss,
     const float* __restrict__ dy_pred, float* __restrict__ de, float* __restrict__ dpre_stash,
     float* __restrict__ wpartial, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z) {
     static_assert(NHID <= 1, "the wide head supports at most one hidden layer");
-    __shared__ __attribute__((aligned(16))) float tile[16][WLS];
-    __shared__ __attribute__((aligned(16))) float tdp[16][WLS];
+    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
-    __shared__ float red[4][16][2];
+    __shared__ __attribute__((aligned(16))) float gacc[2][GCN_WIDE_MAX_H];     // d outW rows 0 and 1
+    __shared__ __attribute__((aligned(16))) float nacc[2][GCN_WIDE_MAX_H];     // BatchNorm-backward sums of the last conv layer
+    __shared__ float red[WNS][4][16][2];
     zero_fill(z);
     const WideIdx ix = wide_idx();
     const int NB = (H + 15) / 16, HP = 16 * NB;
     clds_fill(cl[CL_PMEAN], src.mode == 1 ? src.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], src.mode == 1 ? src.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], src.mode == 1 ? src.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], src.mode == 1 ? src.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], src.mode == 2 ? src.we : nullptr, H, HP);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) { (&gacc[0][0])[k] = 0.f; (&nacc[0][0])[k] = 0.f; }
+    wide_zero_pad(tile, NB, ix.t);
     const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
     const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
     const bool do_next = next.tmp != nullptr;
     const rsrc_t rW = make_rsrc(NHID ? hp.hidW[0] : hp.outW, (uint32_t)H * H * 4);
     const rsrc_t rWt = make_rsrc(NHID ? hidWt : hp.outW, (uint32_t)H * H * 4);
-    const size_t ntiles = (rows + 15) / 16;
+    const size_t ntiles = (rows + 15) / 16, nsteps = (ntiles + WNS - 1) / WNS;
     const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
     const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
     const bool has_loss = (y_edges != nullptr) && voc == 2;
     const float gl = has_loss ? (dloss ? dloss[0] : 1.f) / loss_out[1] : 0.f;
-    f32x4 gw0[WKB], gw1[WKB], na1[WKB], na2[WKB];
-#pragma unroll
-    for (int k = 0; k < WKB; ++k) { gw0[k] = f4zero(); gw1[k] = f4zero(); na1[k] = f4zero(); na2[k] = f4zero(); }
     float gb0 = 0.f, gb1 = 0.f;
     __syncthreads();
-    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        head_src_tile(tile, src, cl, sdc, tl * 16, rows, H, HP, C, e_stash, ix);
+    for (size_t stp = blockIdx.x; stp < nsteps; stp += gridDim.x) {
+        const int ns = (int)min((size_t)WNS, ntiles - stp * WNS);
+#pragma unroll
+        for (int s = 0; s < WNS; ++s)
+            if (s < ns) head_src_tile(tile + 16 * s, src, cl, sdc, (stp * WNS + s) * 16, rows, H, HP, C, e_stash, ix);
         __syncthreads();
-        const size_t row = tl * 16 + ix.rs;
-        const bool rvalid = row < rows;
-        const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
-        f32x4 h[WKB], dmul[WKB];
-        float p0 = 0.f, p1 = 0.f;
+        // ---- first product: hidden pre-activations (with bias), partial logits
+        f32x4 pre[WNS][WKB];
+        float p0[WNS], p1[WNS];
 #pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            const int bcol = 16 * nb + 4 * ix.q;
-            h[k] = f4zero(); dmul[k] = f4zero();
+        for (int s = 0; s < WNS; ++s) { p0[s] = 0.f; p1[s] = 0.f; }
+#pragma unroll 1
+        for (int kk = 0; kk < WKB; ++kk) {
+            const int nb = ix.w + 4 * kk;
+            f32x4 o[WNS];
+#pragma unroll
+            for (int s = 0; s < WNS; ++s) o[s] = f4zero();
             if (nb < NB) {
-                f32x4 pre = NHID ? wide_gemm<true>(tile, rW, H, NB, nb, ix.rs, ix.q) : f4zero();
-                if (bcol < H) {
-                    if (NHID) {
-                        pre += ld4(hp.hidB[0] + bcol);
-                        f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (hdc.on) dm = drop_mul4(hdc, rh, bcol >> 2);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dmul[k][r] = pre[r] > 0.f ? dm[r] : 0.f;
-                            h[k][r] = (pre[r] > 0.f ? pre[r] : 0.f) * dm[r];
-                        }
-                    } else {
-                        h[k] = ld4(&tile[ix.rs][bcol]);
-                        dmul[k] = f32x4{1.f, 1.f, 1.f, 1.f};
-                    }
-                    const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { p0 += h[k][r] * w0[r]; p1 += h[k][r] * w1[r]; }
-                }
-            }
-        }
-        const HeadRowLogits lg = head_row_sum(p0, p1, red, ix);
-        // d logits of this lane's row (every lane of the row computes the same two values)
-        float d0 = 0.f, d1 = 0.f;
-        if (rvalid) {
-            const bool masked = mask_invalid && cap[row / C] == 0.f;
-            if (!masked) {
-                if (voc == 1) {
-                    d0 = dy_pred ? dy_pred[row] : 0.f;
+                const int bcol = 16 * nb + 4 * ix.q;
+                if (NHID) {
+                    wide_gemm_n<0>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, o);
                 } else {
-                    if (has_loss) {
-                        const float l0 = lg.l0 + b2_0, l1 = lg.l1 + b2_1;
-                        const int y = (int)y_edges[row];
-                        const float mx = fmaxf(l0, l1);
-                        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
-                        const float w = (y ? cw1 : cw0) * gl;
-                        d0 = w * (e0 * inv - (y == 0 ? 1.f : 0.f));
-                        d1 = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
-                    }
-                    if (dy_pred) { d0 += dy_pred[row * 2]; d1 += dy_pred[row * 2 + 1]; }
-                }
-            }
-        }
-        if (ix.w == 0 && ix.q == 0) { gb0 += d0; gb1 += d1; }
-        // output layer backward: d outW += d logit x h ; dh = d0 w0 + d1 w1 ; dpre = dh * relu' * dropout
 #pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            const int bcol = 16 * nb + 4 * ix.q;
-            if (nb < NB) {
-                f32x4 dp = f4zero();
+                    for (int s = 0; s < WNS; ++s) o[s] = ld4(&tile[16 * s + ix.rs][bcol]);
+                }
                 if (bcol < H) {
                     const f32x4 w0 = ld4(hp.outW + bcol), w1 = voc > 1 ? ld4(hp.outW + H + bcol) : f4zero();
+                    const f32x4 hb = NHID ? ld4(hp.hidB[0] + bcol) : f4zero();
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        gw0[k][r] += d0 * h[k][r];
-                        gw1[k][r] += d1 * h[k][r];
-                        dp[r] = (d0 * w0[r] + d1 * w1[r]) * dmul[k][r];
-                    }
-                    if (NHID && rvalid) st4(dpre_stash + row * H + bcol, dp);
-                }
-                st4(&tdp[ix.rs][16 * nb + 4 * ix.q], dp);
-            }
-        }
-        __syncthreads();
-        // hidden layer backward: de = dpre W_0 (or dpre itself without a hidden layer); statistics of the last conv layer
-        const uint32_t nrh = (do_next && sdc.on) ? drop_rowhash(sdc, (uint32_t)row) : 0u;
+                    for (int s = 0; s < WNS; ++s) {
+                        if (s < ns) {
+                            o[s] += hb;
+                            f32x4 hv = o[s];
+                            if (NHID) {
 #pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            const int bcol = 16 * nb + 4 * ix.q;
-            if (nb < NB) {
-                const f32x4 dv = NHID ? wide_gemm<true>(tdp, rWt, H, NB, nb, ix.rs, ix.q) : ld4(&tdp[ix.rs][bcol]);
-                if (rvalid && bcol < H) {
-                    st4(de + row * H + bcol, dv);
-                    if (do_next) {
-                        const f32x4 ntp = ld4(next.tmp + row * H + bcol);
-                        const f32x4 nmu = ld4(&cl[CL_PMEAN][bcol]), nrs = ld4(&cl[CL_PRSTD][bcol]);
-                        const f32x4 nga = ld4(&cl[CL_PGAMMA][bcol]), nbe = ld4(&cl[CL_PBETA][bcol]);
-                        f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-                        if (sdc.on) dm = drop_mul4(sdc, nrh, bcol >> 2);
+                                for (int r = 0; r < 4; ++r) hv[r] = hv[r] > 0.f ? hv[r] : 0.f;
+                                if (hdc.on) hv *= drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)((stp * WNS + s) * 16 + ix.rs)), bcol >> 2);
+                            }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float xh = (ntp[r] - nmu[r]) * nrs[r];
-                            const float bn = xh * nga[r] + nbe[r];
-                            const float d = bn > 0.f ? dv[r] * dm[r] : 0.f;
-                            na1[k][r] += d;
-                            na2[k][r] += d * xh;
+                            for (int r = 0; r < 4; ++r) { p0[s] += hv[r] * w0[r]; p1[s] += hv[r] * w1[r]; }
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int s = 0; s < WNS; ++s) { pre[s][0] = o[s]; rot(pre[s]); }
+        }
+        head_row_sums(p0, p1, red, ix);       // its second barrier: every wavefront is done reading the input rows
+        // ---- d logits of this lane's rows (every lane of a row computes the same two values)
+        float d0[WNS], d1[WNS];
+        bool rvalid[WNS];
+#pragma unroll
+        for (int s = 0; s < WNS; ++s) {
+            const size_t row = (stp * WNS + s) * 16 + ix.rs;
+            rvalid[s] = s < ns && row < rows;
+            d0[s] = 0.f; d1[s] = 0.f;
+            if (rvalid[s]) {
+                const bool masked = mask_invalid && cap[row / C] == 0.f;
+                if (!masked) {
+                    if (voc == 1) {
+                        d0[s] = dy_pred ? dy_pred[row] : 0.f;
+                    } else {
+                        if (has_loss) {
+                            const float l0 = p0[s] + b2_0, l1 = p1[s] + b2_1;
+                            const int y = (int)y_edges[row];
+                            const float mx = fmaxf(l0, l1);
+                            const float e0 = expf(l0 - mx), e1 = expf(l1 - mx), inv = 1.f / (e0 + e1);
+                            const float w = (y ? cw1 : cw0) * gl;
+                            d0[s] = w * (e0 * inv - (y == 0 ? 1.f : 0.f));
+                            d1[s] = w * (e1 * inv - (y == 1 ? 1.f : 0.f));
+                        }
+                        if (dy_pred) { d0[s] += dy_pred[row * 2]; d1[s] += dy_pred[row * 2 + 1]; }
+                    }
+                }
+            }
+            if (ix.w == 0 && ix.q == 0) { gb0 += d0[s]; gb1 += d1[s]; }
+        }
+        // ---- output layer backward: d outW += d logit x h ; dh = d0 w0 + d1 w1 ; dpre = dh * relu' * dropout -> LDS
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const bool cok = bcol < H;
+                const f32x4 w0 = cok ? ld4(hp.outW + bcol) : f4zero(), w1 = (cok && voc > 1) ? ld4(hp.outW + H + bcol) : f4zero();
+                f32x4 t0 = f4zero(), t1 = f4zero();
+#pragma unroll
+                for (int s = 0; s < WNS; ++s) {
+                    if (s < ns) {
+                        f32x4 dp = f4zero();
+                        if (cok) {
+                            const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                            const f32x4 pr = pre[s][k];
+                            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (NHID && hdc.on) dm = drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float hv = NHID ? (pr[r] > 0.f ? pr[r] : 0.f) * dm[r] : pr[r];
+                                const float dmul = NHID ? (pr[r] > 0.f ? dm[r] : 0.f) : 1.f;
+                                t0[r] += d0[s] * hv;
+                                t1[r] += d1[s] * hv;
+                                dp[r] = (d0[s] * w0[r] + d1[s] * w1[r]) * dmul;
+                            }
+                            if (NHID && rvalid[s]) st4(dpre_stash + row * H + bcol, dp);
+                        }
+                        st4(&tile[16 * s + ix.rs][bcol], dp);
+                    }
+                }
+                wide_acc_cols(gacc, bcol, ix.rs == 0 && cok, t0, t1);
+            }
+        }
+        __syncthreads();
+        // ---- hidden layer backward: de = dpre W_0 (or dpre itself without a hidden layer); statistics of the last conv layer
+#pragma unroll 1
+        for (int kk = 0; kk < WKB; ++kk) {
+            const int nb = ix.w + 4 * kk;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const bool cok = bcol < H;
+                f32x4 ntp[WNS];
+#pragma unroll
+                for (int s = 0; s < WNS; ++s) {
+                    const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                    ntp[s] = (do_next && rvalid[s] && cok) ? ld4(next.tmp + row * H + bcol) : f4zero();
+                }
+                f32x4 dv[WNS];
+                if (NHID) {
+                    wide_gemm_n<0>(tile, ns, rWt, H, NB, nb, ix.rs, ix.q, dv);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < WNS; ++s) dv[s] = ld4(&tile[16 * s + ix.rs][bcol]);
+                }
+                f32x4 t1 = f4zero(), t2 = f4zero();
+#pragma unroll
+                for (int s = 0; s < WNS; ++s) {
+                    if (rvalid[s] && cok) {
+                        const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                        st4(de + row * H + bcol, dv[s]);
+                        if (do_next) {
+                            const f32x4 nmu = ld4(&cl[CL_PMEAN][bcol]), nrs = ld4(&cl[CL_PRSTD][bcol]);
+                            const f32x4 nga = ld4(&cl[CL_PGAMMA][bcol]), nbe = ld4(&cl[CL_PBETA][bcol]);
+                            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (sdc.on) dm = drop_mul4(sdc, drop_rowhash(sdc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
+                                const float bn = xh * nga[r] + nbe[r];
+                                const float d = bn > 0.f ? dv[s][r] * dm[r] : 0.f;
+                                t1[r] += d;
+                                t2[r] += d * xh;
+                            }
+                        }
+                    }
+                }
+                if (do_next) wide_acc_cols(nacc, bcol, ix.rs == 0 && cok, t1, t2);
             }
         }
         __syncthreads();
@@ -1216,16 +1291,12 @@ __global__ __launch_bounds__(256) void k_head_bwd_w(
     for (int k = 0; k < WKB; ++k) {
         const int nb = ix.w + 4 * k;
         const int bcol = 16 * nb + 4 * ix.q;
-        if (nb < NB) {
-            const f32x4 g0 = red16x4(gw0[k]), g1 = red16x4(gw1[k]);
-            const f32x4 t1 = red16x4(na1[k]), t2 = red16x4(na2[k]);
-            if (ix.rs == 0 && bcol < H) {
-                st4(wp + bcol, g0);
-                if (voc > 1) st4(wp + H + bcol, g1);
-                if (do_next) {
-                    st4(next.partial + (size_t)blockIdx.x * 2 * H + bcol, t1);
-                    st4(next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, t2);
-                }
+        if (nb < NB && ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+            st4(wp + bcol, ld4(&gacc[0][bcol]));
+            if (voc > 1) st4(wp + H + bcol, ld4(&gacc[1][bcol]));
+            if (do_next) {
+                st4(next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nacc[0][bcol]));
+                st4(next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nacc[1][bcol]));
             }
         }
     }
