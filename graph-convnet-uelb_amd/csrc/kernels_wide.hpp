@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_node_fwd_w(NodeFwdArgs a) {
             const bool valid = rowb < a.rows && bcol < H;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                f32x4 o = wide_gemm(tile, rW[k], H, NB, nb, ix.rs, ix.q);
+                f32x4 o = wide_gemm<true>(tile, rW[k], H, NB, nb, ix.rs, ix.q);
                 if (valid) st4(a.y[k] + (size_t)rowb * H + bcol, o + ld4(a.bias[k] + bcol));
             }
         }
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_node_bwd_w(NodeBwdArgs a) {
             for (int k = 0; k < WKB; ++k) {
                 const int nb = ix.w + 4 * k;
                 if (nb < NB) {
-                    const f32x4 o = wide_gemm(tile, rW, H, NB, nb, ix.rs, ix.q);
+                    const f32x4 o = wide_gemm<true>(tile, rW, H, NB, nb, ix.rs, ix.q);
                     acc[k] = pass == 0 ? o : acc[k] + o;
                 }
             }
