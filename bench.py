@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-beam", action="store_true")
+    ap.add_argument("--skip-opt", action="store_true", help="skip the extra leg that adds the optimizer step")
     args = ap.parse_args()
 
     from src.common.synthetic import CONFIGS, make_batch
@@ -292,6 +293,39 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # ---- the same steps followed by the optimizer (multi-tensor Adam of the library), reported beside the headline:
+    # the metric itself is forward + backward (+ gradient all-reduce), as the baseline names it
+    with_opt = None
+    if not args.skip_opt:
+        from src.gcn.hip.fused_adam import FusedAdam
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+
+        def full_step():
+            one_step()
+            opt.step()
+
+        for _ in range(max(1, min(args.warmup, 5))):
+            full_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            allreduce(t, dist.ReduceOp.MAX)
+            el = float(t.item())
+        with_opt = {"optimizer": "Adam (gcn_adam_step, one launch for all parameters)",
+                    "ms_per_step": round(el / args.steps * 1e3, 4), "graphs_per_s": round(world * B * args.steps / el, 1)}
+        _stage("steps with optimizer done")
+
     # ---- dominant kernel, timed with HIP events around each of its launches (eager pass, rank 0)
     roofline = None
     if rank == 0:
@@ -343,7 +377,7 @@ def main():
                                    f"{'HIP graph replay' if not args.no_graph else 'eager launches'}",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 5),
-            "roofline": roofline,
+            "roofline": roofline, "with_optimizer": with_opt,
         }
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(shape, batch)
