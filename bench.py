@@ -85,9 +85,10 @@ def cpu_baseline(shape, batch, max_seconds=25.0):
         loss.backward()
 
     one()                                     # warm-up
+    # a bounded sample: about 12 s of CPU work (at most 60 steps), at least two steps however long they take
     times = []
-    t_end = time.time() + max_seconds
-    while len(times) < 5 and (time.time() < t_end or len(times) < 2):
+    t_end = time.time() + min(max_seconds, 12.0)
+    while len(times) < 60 and (time.time() < t_end or len(times) < 2):
         t0 = time.time()
         one()
         times.append(time.time() - t0)
