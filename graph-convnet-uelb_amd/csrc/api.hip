@@ -107,7 +107,7 @@ Dims make_dims(int B, int V, int C, int H) {
     d.njt = (V + 15) / 16;
     // enough (b, c, i-chunk, j-tile) units to give every SIMD of the chip a wavefront
     const long long fine = (long long)B * C * d.njt * V;
-    d.IT = (int)std::max<long long>(1, std::min<long long>(V, fine / 1024));
+    d.IT = (int)std::max<long long>(1, std::min<long long>(V, (fine + 512) / 1024));   // about 1024 units (nearest: 3 rows at nsfnet_10 measured 1.2 % faster than 2)
     if (const char* e = getenv("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
     // chunks of equal length (68 + 32 rows at V = 100 would leave half of the workgroups with twice the work); a
