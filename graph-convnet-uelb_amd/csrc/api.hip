@@ -197,10 +197,16 @@ int red_grid(const ReduceJobs& jobs) {
     return g;
 }
 
-int tn_slices(size_t rows) {
+// Row slices of a weight-gradient product (one partial H x H slab each, added up afterwards).  Strip path: the cost is
+// (rows per slice) + (slices to add up), so the count grows with the square root of the rows; 3.8 sqrt(tiles) matches the
+// measured optima (192 / 256 / 384 slices at 2,450 / 4,900 / 10,000 row tiles).  Wide path: one 512-thread workgroup per
+// slice, one slice per CU.
+int tn_slices(size_t rows, int H) {
     const size_t ntiles = (rows + 15) / 16;
-    static const int cap = getenv("GCN_TUNE_SLICES") ? atoi(getenv("GCN_TUNE_SLICES")) : 256;
-    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)cap));
+    if (const char* e = getenv("GCN_TUNE_SLICES")) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)atoi(e)));
+    if (H > 64) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
+    const size_t s = ((size_t)(3.8 * std::sqrt((double)ntiles)) + 8) / 16 * 16;
+    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, std::min<size_t>(std::max<size_t>(s, 16), 512)));
 }
 
 constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
@@ -213,8 +219,8 @@ struct LayerBwdWs {
 LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
     LayerBwdWs w;
     const size_t nh = d.Rn * d.H;
-    w.S_e = tn_slices(d.Re);
-    w.S_n = tn_slices(d.Rn);
+    w.S_e = tn_slices(d.Re, d.H);
+    w.S_n = tn_slices(d.Rn, d.H);
     w.det = b.f(d.Re * d.H);
     w.bpart_e = b.f((size_t)kMaxPartBlocks * 2 * d.H);
     w.bpart_x = b.f((size_t)kMaxPartBlocks * 2 * d.H);
@@ -612,7 +618,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     w.h_stash = p.NHID > 1 ? b.f((size_t)(p.NHID - 1) * eh) : nullptr;
     w.head_blk = wave_blocks((p.d.Re + 15) / 16);
     w.wpartial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * (size_t)((p.voc * p.d.H + p.voc + 3) & ~3));
-    w.S_h = tn_slices(p.d.Re);
+    w.S_h = tn_slices(p.d.Re, p.d.H);
     w.tn_h = b.f((size_t)w.S_h * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));
     w.emb_blk = wave_blocks((p.d.Re + 15) / 16);
     w.embpart = b.f((size_t)w.emb_blk * GCN_WAVES_PER_BLOCK * p.d.H);
