@@ -206,7 +206,7 @@ int tn_slices(size_t rows, int H) {
     if (const char* e = getenv("GCN_TUNE_SLICES")) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)atoi(e)));
     if (H > 64) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
     const size_t s = ((size_t)(3.8 * std::sqrt((double)ntiles)) + 8) / 16 * 16;
-    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, std::min<size_t>(std::max<size_t>(s, 16), 512)));
+    return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, std::min<size_t>(std::max<size_t>(s, 16), 768)));   // 768: flat beyond at 10^6 row tiles
 }
 
 constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
