@@ -135,6 +135,13 @@ inline int wave_blocks(size_t units, int cap = 512) {
 }
 // persistent grid of the edge kernels: 256 compute units x 2 resident workgroups (more did not run faster: the kernels are issue bound)
 constexpr int kEdgeGrid = 512;
+// Workgroups of the two edge kernels: two per CU; three per CU on the strip path once a workgroup has more than about
+// ten 16-row steps to walk (measured: 512 is best at nsfnet_10 with 2,800 steps in all, 768 from nsfnet_20's 5,600 up;
+// the 200-node configuration gains 4 %).  The wide kernels are built for two workgroups per CU.
+inline int edge_grid(const Dims& d) {
+    const long long steps = (long long)d.B * d.C * d.njt * d.V;
+    return (d.H <= 64 && steps >= 5000) ? 768 : kEdgeGrid;
+}
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
 // grid of a kernel whose workgroups each take a contiguous range of units: no workgroup is left without work
@@ -181,7 +188,7 @@ struct LayerFwdWs {
 };
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
-    w.nblk = range_blocks(d.Rn, kEdgeGrid);
+    w.nblk = range_blocks(d.Rn, edge_grid(d));
     if (const char* e = getenv("GCN_TUNE_GRID_F")) w.nblk = range_blocks(d.Rn, std::min(atoi(e), 2048));
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
@@ -372,7 +379,7 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
         a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
     }
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-    int blocks = range_blocks(units, kEdgeGrid);
+    int blocks = range_blocks(units, edge_grid(d));
     if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
     if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
     else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
