@@ -105,15 +105,30 @@ Dims make_dims(int B, int V, int C, int H) {
     d.Rn = (size_t)B * V * C;
     d.Re = d.Rn * V;
     d.njt = (V + 15) / 16;
-    // enough (b, c, i-chunk, j-tile) units to give every SIMD of the chip a wavefront
+    // Row chunks of the edge backward pass: about 1024 (b, c, i-chunk, j-tile) units, chunks of equal length (68 + 32
+    // rows at V = 100 would leave half of the workgroups with twice the work).
     const long long fine = (long long)B * C * d.njt * V;
-    d.IT = (int)std::max<long long>(1, std::min<long long>(V, (fine + 512) / 1024));   // about 1024 units (nearest: 3 rows at nsfnet_10 measured 1.2 % faster than 2)
+    const int target = (int)std::max<long long>(1, std::min<long long>(V, (fine + 512) / 1024));
+    auto balanced = [&](int it) { const int n = (V + it - 1) / it; return (V + n - 1) / n; };
+    d.IT = balanced(target);
+    if (H <= 64) {
+        // Strip path: the kernel is issue bound, so a launch lasts as long as the busiest CU has steps to issue:
+        // (workgroups on that CU) x (units per workgroup) x (rows per unit).  Among the chunk lengths within a factor
+        // of two of the target, take the one with the fewest such steps, the nearest to the target on a tie.  (Measured:
+        // default2 picks 8 rows instead of 10 and runs 5 % faster; nsfnet_20 3 instead of 5, 1 %; nsfnet_10 stays at 3.)
+        const int grid = fine >= 5000 ? 768 : 512;          // as edge_grid() below
+        long long best = -1;
+        for (int it = std::max(1, target / 2); it <= std::min(V, 2 * target); ++it) {
+            if (balanced(it) != it) continue;
+            const long long units = (long long)B * ((V + it - 1) / it) * d.njt * C;
+            const long long per = (units + grid - 1) / grid, active = (units + per - 1) / per;
+            const long long cost = ((active + 255) / 256) * per * it;
+            if (best < 0 || cost < best || (cost == best && std::abs(it - target) < std::abs(d.IT - target))) { best = cost; d.IT = it; }
+        }
+    } else if (d.IT > 3) {
+        d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
+    }
     if (const char* e = getenv("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
-    d.nit = (V + d.IT - 1) / d.IT;
-    // chunks of equal length (68 + 32 rows at V = 100 would leave half of the workgroups with twice the work); a
-    // multiple of three where the wide kernel walks the rows of a chunk three at a time
-    d.IT = (V + d.nit - 1) / d.nit;
-    if (H > 64 && d.IT > 3) d.IT = std::min(V, (d.IT + 2) / 3 * 3);
     d.nit = (V + d.IT - 1) / d.IT;
     d.MT = (H + 15) / 16;
     return d;
