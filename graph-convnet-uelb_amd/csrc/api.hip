@@ -96,6 +96,7 @@ struct Dims {
     size_t Re, Rn;   // edge rows, node rows
     int njt;         // 16-row j tiles per (b, i, c)
     int IT, nit;     // i-chunk length / count of the edge backward pass
+    int grid_f, grid_b;   // workgroups of the forward / backward edge kernel (upper bounds: no workgroup is left without work)
     int MT;
 };
 
@@ -111,20 +112,30 @@ Dims make_dims(int B, int V, int C, int H) {
     const int target = (int)std::max<long long>(1, std::min<long long>(V, (fine + 512) / 1024));
     auto balanced = [&](int it) { const int n = (V + it - 1) / it; return (V + n - 1) / n; };
     d.IT = balanced(target);
+    d.grid_f = d.grid_b = 512;                              // two workgroups per CU
     if (H <= 64) {
-        // Strip path: the kernel is issue bound, so a launch lasts as long as the busiest CU has steps to issue:
-        // (workgroups on that CU) x (units per workgroup) x (rows per unit).  Among the chunk lengths within a factor
-        // of two of the target, take the one with the fewest such steps, the nearest to the target on a tie.  (Measured:
-        // default2 picks 8 rows instead of 10 and runs 5 % faster; nsfnet_20 3 instead of 5, 1 %; nsfnet_10 stays at 3.)
-        const int grid = fine >= 5000 ? 768 : 512;          // as edge_grid() below
-        long long best = -1;
-        for (int it = std::max(1, target / 2); it <= std::min(V, 2 * target); ++it) {
-            if (balanced(it) != it) continue;
-            const long long units = (long long)B * ((V + it - 1) / it) * d.njt * C;
+        // Strip path: the edge kernels are issue bound, so a launch lasts as long as the busiest CU has 16-row steps to
+        // issue: (workgroups on that CU) x (units per workgroup) x (steps per unit).  Grid (two or three workgroups per
+        // CU) and chunk length (within a factor of two of the target) are the pair with the fewest such steps; on a
+        // tie, three per CU once there are many steps per workgroup, and the chunk length nearest to the target.
+        // (Measured against the fixed choice 512 / target: default2 8 rows instead of 10, 5 % faster; nsfnet_20 2 rows
+        // instead of 5 and 512 forward workgroups instead of 768, 3 %; nsfnet_10 unchanged at 512 / 512 / 3 rows.)
+        const int pref = fine >= 5000 ? 768 : 512;
+        auto busiest = [](long long units, int grid, long long steps_per_unit) {
             const long long per = (units + grid - 1) / grid, active = (units + per - 1) / per;
-            const long long cost = ((active + 255) / 256) * per * it;
-            if (best < 0 || cost < best || (cost == best && std::abs(it - target) < std::abs(d.IT - target))) { best = cost; d.IT = it; }
-        }
+            return ((active + 255) / 256) * per * steps_per_unit;
+        };
+        const int grids[2] = {pref, pref == 768 ? 512 : 768};
+        long long best = -1;
+        for (int g : grids)
+            for (int it = std::max(1, target / 2); it <= std::min(V, 2 * target); ++it) {
+                if (balanced(it) != it) continue;
+                const long long cost = busiest((long long)B * ((V + it - 1) / it) * d.njt * C, g, it);
+                if (best < 0 || cost < best || (cost == best && g == d.grid_b && std::abs(it - target) < std::abs(d.IT - target))) {
+                    best = cost; d.IT = it; d.grid_b = g;
+                }
+            }
+        d.grid_f = busiest((long long)d.Rn, grids[1], d.njt) < busiest((long long)d.Rn, grids[0], d.njt) ? grids[1] : grids[0];
     } else if (d.IT > 3) {
         d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
     }
@@ -147,15 +158,6 @@ int check_dims(int B, int V, int C, int H) {
 
 inline int wave_blocks(size_t units, int cap = 512) {
     return (int)std::max<size_t>(1, std::min<size_t>((units + GCN_WAVES_PER_BLOCK - 1) / GCN_WAVES_PER_BLOCK, (size_t)cap));
-}
-// persistent grid of the edge kernels: 256 compute units x 2 resident workgroups (more did not run faster: the kernels are issue bound)
-constexpr int kEdgeGrid = 512;
-// Workgroups of the two edge kernels: two per CU; three per CU on the strip path once a workgroup has more than about
-// ten 16-row steps to walk (measured: 512 is best at nsfnet_10 with 2,800 steps in all, 768 from nsfnet_20's 5,600 up;
-// the 200-node configuration gains 4 %).  The wide kernels are built for two workgroups per CU.
-inline int edge_grid(const Dims& d) {
-    const long long steps = (long long)d.B * d.C * d.njt * d.V;
-    return (d.H <= 64 && steps >= 5000) ? 768 : kEdgeGrid;
 }
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
@@ -203,7 +205,7 @@ struct LayerFwdWs {
 };
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
-    w.nblk = range_blocks(d.Rn, edge_grid(d));
+    w.nblk = range_blocks(d.Rn, d.grid_f);
     if (const char* e = getenv("GCN_TUNE_GRID_F")) w.nblk = range_blocks(d.Rn, std::min(atoi(e), 2048));
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
@@ -394,7 +396,7 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
         a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
     }
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-    int blocks = range_blocks(units, edge_grid(d));
+    int blocks = range_blocks(units, d.grid_b);
     if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
     if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
     else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
