@@ -192,12 +192,16 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-beam", action="store_true")
     ap.add_argument("--skip-opt", action="store_true", help="skip the extra leg that adds the optimizer step")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the broadcast / all-reduce even with one rank "
+                         "(executes the RCCL path on a single GPU)")
     args = ap.parse_args()
 
     from src.common.synthetic import CONFIGS, make_batch
     from src.gcn.hip import lib as L
     from src.gcn.hip.train_step import HipTrainStep
 
+    from src.gcn.hip import dist as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -205,7 +209,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
-    if world > 1:
+    backend = None
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -221,6 +226,7 @@ def main():
         else:
             local_rank = local_rank % ndev
             dist.init_process_group(backend, rank=rank, world_size=world)
+        D.RUN_SINGLE_RANK_COLLECTIVES = bool(args.force_dist)     # one rank: still broadcast and all-reduce
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     _stage(f"process group ready, device {device}")
@@ -232,43 +238,21 @@ def main():
     batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
                        seed=1234 + rank)
     model = build_model(shape, device).train()          # train mode: dropout active, as the trainer runs
-    staged = dist is not None and dist.get_backend() != "nccl"      # rehearsal backend: collectives go through host copies
-
-    def bcast(t):
-        if staged:
-            c = t.detach().cpu()
-            dist.broadcast(c, src=0)
-            t.copy_(c)
-        else:
-            dist.broadcast(t, src=0)
-
-    def allreduce(t, op=None):
-        op = dist.ReduceOp.SUM if op is None else op
-        if staged:
-            c = t.detach().cpu()
-            dist.all_reduce(c, op=op)
-            t.copy_(c)
-        else:
-            dist.all_reduce(t, op=op)
-
     if dist is not None:
-        for p in model.parameters():
-            bcast(p.data)
+        D.broadcast_parameters(model.parameters())
         # class weights: one set for the whole job (rank 0's), as the trainer uses global weights for every shard
         cw = torch.from_numpy(np.asarray(batch["edge_cw"], dtype=np.float32)).to(device)
-        bcast(cw)
+        D.broadcast_(cw)
         batch["edge_cw"] = cw.cpu().numpy()
     _stage("parameters broadcast")
     step = HipTrainStep(model, B, device, use_graph=not args.no_graph)
     step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
                     batch["edges_target"], batch["edge_cw"])
-    inv_world = 1.0 / world
 
     def one_step():
         step.step()
         if dist is not None:
-            allreduce(step.flat_grad)
-            step.flat_grad.mul_(inv_world)
+            D.allreduce_mean_(step.flat_grad)       # one message; on RCCL the 1/N is part of the collective (AVG)
 
     for _ in range(args.warmup):
         one_step()
@@ -287,7 +271,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        allreduce(t, dist.ReduceOp.MAX)
+        D.allreduce_max_(t)
         elapsed = float(t.item())
     _stage("timed steps done")
     loss = float(step.loss_out[0].item())
@@ -321,7 +305,7 @@ def main():
         el = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=device)
-            allreduce(t, dist.ReduceOp.MAX)
+            D.allreduce_max_(t)
             el = float(t.item())
         with_opt = {"optimizer": "Adam (gcn_adam_step, one launch for all parameters)",
                     "ms_per_step": round(el / args.steps * 1e3, 4), "graphs_per_s": round(world * B * args.steps / el, 1)}
@@ -378,6 +362,11 @@ def main():
                                    f"{'HIP graph replay' if not args.no_graph else 'eager launches'}",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 5),
+            # ranks of the RCCL (backend "nccl") process group the gradient all-reduce ran on; 0 = no process group
+            "rccl_ranks": D.rccl_ranks(),
+            "gradient_allreduce": None if dist is None else {
+                "backend": backend, "op": "all_reduce AVG" if backend == "nccl" else "all_reduce SUM, host-staged",
+                "bytes": int(step.flat_grad.numel()) * 4, "per_step": 1},
             "roofline": roofline, "with_optimizer": with_opt,
         }
         if world == 1 and not args.skip_cpu:

@@ -25,6 +25,14 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+// Measurement overrides (grid sizes, chunk lengths, probes) exist only in builds made with -DGCN_TUNING
+// (tools/build_tuning_lib.sh); the product library reads no environment variable.
+#ifdef GCN_TUNING
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -139,7 +147,7 @@ Dims make_dims(int B, int V, int C, int H) {
     } else if (d.IT > 3) {
         d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
     }
-    if (const char* e = getenv("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
+    if (const char* e = tune_env("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
     d.MT = (H + 15) / 16;
     return d;
@@ -206,7 +214,7 @@ struct LayerFwdWs {
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
     w.nblk = range_blocks(d.Rn, d.grid_f);
-    if (const char* e = getenv("GCN_TUNE_GRID_F")) w.nblk = range_blocks(d.Rn, std::min(atoi(e), 2048));
+    if (const char* e = tune_env("GCN_TUNE_GRID_F")) w.nblk = range_blocks(d.Rn, std::min(atoi(e), 2048));
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
     w.partial = b.f((size_t)w.nblk * 4 * d.H);
@@ -227,7 +235,7 @@ int red_grid(const ReduceJobs& jobs) {
 // slice, one slice per CU.
 int tn_slices(size_t rows, int H) {
     const size_t ntiles = (rows + 15) / 16;
-    if (const char* e = getenv("GCN_TUNE_SLICES")) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)atoi(e)));
+    if (const char* e = tune_env("GCN_TUNE_SLICES")) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)atoi(e)));
     if (H > 64) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
     const size_t s = ((size_t)(3.8 * std::sqrt((double)ntiles)) + 8) / 16 * 16;
     return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, std::min<size_t>(std::max<size_t>(s, 16), 768)));   // 768: flat beyond at 10^6 row tiles
@@ -312,7 +320,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.src = make_edge_src(pv, e_in, e_in_out, H, p, training);
         a.WU = P[4]; a.bU = P[5]; a.Ve = W.Ve; a.Vn = S.Vn; a.Ux = W.Ux;
         a.e_tmp = S.e_tmp; a.x_tmp = S.x_tmp; a.Aout = S.A; a.Dout = S.D; a.partial = W.partial; a.rng = rng;
-        if (const char* e = getenv("GCN_TUNE_PROBE")) a.probe = atoi(e);
+        if (const char* e = tune_env("GCN_TUNE_PROBE")) a.probe = atoi(e);
         const bool one = d.V <= 16;
         if constexpr (MT == 0) {
             GCN_LAUNCH_TIMED("k_edge_fwd_w", k_edge_fwd_w, W.nblk, 256, a);
@@ -397,7 +405,7 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
     }
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
     int blocks = range_blocks(units, d.grid_b);
-    if (const char* e = getenv("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
+    if (const char* e = tune_env("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
     if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
     else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
     if (nx.on) npart_e = blocks;
@@ -574,7 +582,7 @@ ModelPlan make_plan(const gcn_model_desc* m) {
     p.L = m->L; p.NHID = m->mlp_layers - 1; p.voc = m->voc_out; p.n_emb = m->n_emb;
     // the workgroup-per-tile head kernels (one partial row per workgroup): k_head_*_w above H = 64, k_head_*3 up to
     // one hidden layer below it; deeper heads at H <= 64 use the wavefront-per-tile kernels
-    p.whead = p.d.MT > 4 || (p.NHID <= 1 && getenv("GCN_TUNE_OLDHEAD") == nullptr);
+    p.whead = p.d.MT > 4 || (p.NHID <= 1 && tune_env("GCN_TUNE_OLDHEAD") == nullptr);
     p.nparams = 3 + GCN_LAYER_NPARAMS * m->L + 2 * m->mlp_layers;
     const size_t nh = p.d.Rn * p.d.H, eh = p.d.Re * p.d.H;
     p.lsaved_each = layer_saved_floats(p.d);
@@ -776,6 +784,18 @@ int gcn_prof_end(double* total_ms, int* launches) {
     return 0;
 }
 
+int gcn_layer_plan(int B, int V, int C, int H, int out[8]) {
+    if (int rc = check_dims(B, V, C, H)) return rc;
+    if (!out) return fail(-1, "gcn_layer_plan: null output");
+    const Dims d = make_dims(B, V, C, H);
+    Bump f(nullptr, 0);
+    const LayerFwdWs fw = carve_fwd_ws(d, f);
+    const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
+    out[0] = d.IT; out[1] = d.nit; out[2] = d.njt; out[3] = fw.nblk; out[4] = range_blocks(units, d.grid_b);
+    out[5] = d.MT > 4 ? 1 : 0; out[6] = 0; out[7] = 0;
+    return 0;
+}
+
 size_t gcn_layer_saved_floats(int B, int V, int C, int H) {
     if (check_dims(B, V, C, H)) return 0;
     return layer_saved_floats(make_dims(B, V, C, H));
@@ -840,6 +860,33 @@ size_t gcn_model_ws_bytes(const gcn_model_desc* m) {
     carve_model_fwd(p, f);
     carve_model_bwd(p, b);
     return std::max(f.off, b.off);
+}
+
+int gcn_model_saved_layout(const gcn_model_desc* m, int layer, size_t out[8]) {
+    if (int rc = check_model(m)) return rc;
+    if (!out) return fail(-1, "gcn_model_saved_layout: null output");
+    if (layer < 0 || layer >= m->L) return fail(-1, "gcn_model_saved_layout: layer %d outside 0..%d", layer, m->L - 1);
+    const ModelPlan p = make_plan(m);
+    const size_t nh = p.d.Rn * p.d.H, eh = p.d.Re * p.d.H;
+    const size_t base = p.lsaved + (size_t)layer * p.lsaved_each;
+    out[0] = base;                       // the order of carve_saved: e_tmp, x_tmp, A, D, Vn, stats
+    out[1] = base + eh;
+    out[2] = base + eh + 4 * nh;
+    out[3] = p.e_act + (size_t)layer * eh;
+    out[4] = p.x_act + (size_t)layer * nh;
+    out[5] = 0; out[6] = 0; out[7] = 0;
+    return 0;
+}
+
+int gcn_bn_relu_pattern(size_t rows, int H, const float* tmp, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, unsigned char* mask, void* stream) {
+    if (rows == 0 || H <= 0 || H % 4 != 0) return fail(-1, "gcn_bn_relu_pattern: rows and H must be positive, H a multiple of 4");
+    if (!tmp || !mean || !rstd || !gamma || !beta || !mask) return fail(-1, "gcn_bn_relu_pattern: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    GCN_PROF_PRE("k_bn_relu_pattern");
+    k_bn_relu_pattern<<<elem_blocks(rows * (size_t)(H / 4)), 256, 0, st>>>(rows, H, tmp, mean, rstd, gamma, beta, mask);
+    GCN_CHECK_LAUNCH("k_bn_relu_pattern");
+    return 0;
 }
 
 int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand, const long long* x_nodes,

@@ -103,6 +103,31 @@ __global__ void k_bn_apply(size_t rows, int H, const float* __restrict__ tmp, co
     }
 }
 
+// mask[row][h] = 1 iff the ReLU behind a BatchNorm is open at that element, decided by the expression every
+// kernel of the library uses for it: (tmp - mean) * rstd * gamma + beta > 0 (a subtraction, a product, one fused
+// multiply-add).  For tests that hand the library's own ReLU decisions to a reference implementation.
+__global__ void k_bn_relu_pattern(size_t rows, int H, const float* __restrict__ tmp, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, unsigned char* __restrict__ mask) {
+    const int h4 = H / 4;
+    const size_t n4 = rows * (size_t)h4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / h4;
+        const int col = (int)(i - row * h4) * 4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tmp + row * H + col);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + col);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + col);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
+        uchar4 m;
+        m.x = ((t[0] - mu[0]) * rs[0] * ga[0] + be[0]) > 0.f ? 1 : 0;
+        m.y = ((t[1] - mu[1]) * rs[1] * ga[1] + be[1]) > 0.f ? 1 : 0;
+        m.z = ((t[2] - mu[2]) * rs[2] * ga[2] + be[2]) > 0.f ? 1 : 0;
+        m.w = ((t[3] - mu[3]) * rs[3] * ga[3] + be[3]) > 0.f ? 1 : 0;
+        *reinterpret_cast<uchar4*>(mask + row * H + col) = m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Edge MLP head + loss partials.  MLP.forward (gcn_layers.py:167-176) with NHID = mlp_layers - 1
 // hidden Linear(H,H)+ReLU+Dropout blocks, then Linear(H, voc); optional -1e9 masking of zero-capacity

@@ -138,6 +138,11 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
     const uint32_t voffN = bcol_ok ? (uint32_t)bcol * 4 : kOob;                   // lane offset in one node row
     const uint32_t voffL = lead ? (uint32_t)bcol * 4 : kOob;                      // same, leading lanes only
     const EdgeSrc& S = a.src;
+#ifdef GCN_TUNING
+    const int probe = a.probe;         // measurement builds only: bit k drops one stream of memory traffic
+#else
+    constexpr int probe = 0;
+#endif
     edge_src_fill_consts<MT>(cl, S, H);
     const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && MODE == 1);
     f32x4 psx1 = f4zero(), psx2 = f4zero();
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
     auto tile_bytes = [&](int jt_) { return (uint32_t)(min(16, V - jt_ * 16) - 1) * rowb + hb; };
     auto load_raw = [&](int bi_, int c_, int jt_) {
         const uint32_t erow0 = (uint32_t)(bi_ * V + jt_ * 16) * C + c_;
-        const uint32_t nb = (a.probe & 1) ? 0u : tile_bytes(jt_);
+        const uint32_t nb = (probe & 1) ? 0u : tile_bytes(jt_);
         if constexpr (MODE == 0) ra = bld4(make_rsrc(rowp(S.e_in, erow0), nb), voffA);
         if constexpr (MODE == 1) { ra = bld4(make_rsrc(rowp(S.prev_tmp, erow0), nb), voffA); rb = bld4(make_rsrc(rowp(S.prev_in, erow0), nb), voffA); }
         if constexpr (MODE == 2)
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) val[k] = valid ? val[k] : 0.f;
-            if constexpr (MODE != 0) bst4(make_rsrc(rowpw(S.e_out, erow0), (a.probe & 2) ? 0u : nbytes), voffA, val);
+            if constexpr (MODE != 0) bst4(make_rsrc(rowpw(S.e_out, erow0), (probe & 2) ? 0u : nbytes), voffA, val);
             st4(&tile[buf][arow][acol], val);
         }
         // ---- next step's coordinates
@@ -228,8 +233,8 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
         const f32x4 vei_n = bld4(make_rsrc(rowp(a.Ve, nu), hb), voffN);
         const f32x4 uxv_n = bld4(make_rsrc(rowp(a.Ux, nu), hb), voffN);
         const uint32_t n0 = (uint32_t)(b * V + jt * 16) * C + c;                 // node row (b, 16 jt, c)
-        const f32x4 vej = bld4(make_rsrc(rowp(a.Ve, n0), (a.probe & 8) ? 0u : nbytes), voffB);
-        const f32x4 vnj = bld4(make_rsrc(rowp(a.Vn, n0), (a.probe & 8) ? 0u : nbytes), voffB);
+        const f32x4 vej = bld4(make_rsrc(rowp(a.Ve, n0), (probe & 8) ? 0u : nbytes), voffB);
+        const f32x4 vnj = bld4(make_rsrc(rowp(a.Vn, n0), (probe & 8) ? 0u : nbytes), voffB);
         load_raw(nbi, nc, njt2);
         GCN_STAMP(2);
         __syncthreads();
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_fwd3(EdgeFwdArgs a) {
         asm volatile("" : "+v"(et));
         GCN_STAMP(5);
 #endif
-        bst4(make_rsrc(rowpw(a.e_tmp, erow0), (a.probe & 4) ? 0u : nbytes), voffB, et);
+        bst4(make_rsrc(rowpw(a.e_tmp, erow0), (probe & 4) ? 0u : nbytes), voffB, et);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = valid ? et[r] : 0.f;
@@ -560,8 +565,9 @@ __device__ __forceinline__ void st4_dev(float* p, const f32x4& v) {
 // ([nb][ncols], ncols <= 32 * MT, a multiple of 4) with st4_dev.  Returns true in the last workgroup to arrive, with
 // the column sums in tot[0 .. ncols) (LDS, 8 * 32 * MT doubles of scratch).  The sums are formed in a fixed order
 // (eight interleaved row groups per column, then a tree over the groups), so which workgroup arrives last does
-// not matter.  Ordering: every value handed between workgroups is stored and loaded at device scope; a
-// workgroup-scope release fence (wait for the stores to be acknowledged) plus the barrier orders them before the
+// not matter.  Ordering: every value handed between workgroups is stored and loaded at device scope (sc1,
+// written through).  Each wavefront waits for its own stores to be acknowledged with an explicit s_waitcnt vmcnt(0)
+// (a workgroup-scope fence emits no such wait on gfx950), the barrier then orders all of them before the
 // device-scope increment of the arrival counter, and the reader takes its ticket before it loads.
 // The loads of one thread are issued in batches of twelve: up to 96 rows the tail costs one ticket and one round of loads.
 template <int MT>
@@ -569,6 +575,7 @@ __device__ __forceinline__ bool last_block_totals(const LastBlockFinish& f, cons
     constexpr int CG = 8 * MT;                 // column groups of four
     int* ticket = reinterpret_cast<int*>(tot);
     const int t = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's st4_dev stores have reached memory
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (t == 0) *ticket = __hip_atomic_fetch_add(f.counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -39,7 +39,7 @@ def _staged(t):
 
 
 def broadcast_(t, src=0, group=None):
-    if world() > 1:
+    if active() and (world() > 1 or RUN_SINGLE_RANK_COLLECTIVES):
         if _staged(t):
             c = t.detach().cpu()
             dist.broadcast(c, src=src, group=group)
@@ -61,18 +61,53 @@ def allreduce_sum_(t, group=None):
 
 
 def broadcast_parameters(params, src=0):
-    if world() > 1:
-        for p in params:
-            broadcast_(p.data, src=src)
+    for p in params:
+        broadcast_(p.data, src=src)
+
+
+# Set by callers that want the collectives to execute even in a one-rank process group (bench.py --force-dist:
+# the RCCL path then runs on a single GPU exactly as it does on eight).
+RUN_SINGLE_RANK_COLLECTIVES = False
+
+
+def active():
+    return dist.is_available() and dist.is_initialized()
+
+
+def rccl_ranks():
+    """Ranks of the process group when it runs on RCCL (backend "nccl"), else 0."""
+    return dist.get_world_size() if active() and dist.get_backend() == "nccl" else 0
 
 
 def allreduce_mean_(flat, group=None):
-    """In-place mean over ranks of a flat tensor (the whole gradient in one message)."""
+    """In-place mean over ranks of a flat tensor (the whole gradient in one message).  On RCCL the division is
+    part of the collective (ReduceOp.AVG): no separate scaling launch.  Staged (gloo) copies divide on the host."""
+    if not active():
+        return flat
     w = world()
-    if w > 1:
-        allreduce_sum_(flat, group)
+    if w == 1 and not RUN_SINGLE_RANK_COLLECTIVES:
+        return flat
+    if flat.is_cuda and dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    elif _staged(flat):
+        c = flat.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(c.mul_(1.0 / w))
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.mul_(1.0 / w)
     return flat
+
+
+def allreduce_max_(t, group=None):
+    if active() and (world() > 1 or RUN_SINGLE_RANK_COLLECTIVES):
+        if _staged(t):
+            c = t.detach().cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
 
 
 def allreduce_mean_grads(params, group=None):

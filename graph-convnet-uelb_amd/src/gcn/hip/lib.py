@@ -14,13 +14,38 @@ import torch
 
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 LIB_PATH = os.environ.get("GCN_UELB_LIB") or os.path.join(_PKG_ROOT, "lib", "libgcn_uelb_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_H = 320
 LAYER_NPARAMS = 12
 
 
 class GcnHipError(RuntimeError):
     pass
+
+
+BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def source_files():
+    """The files the library is built from: csrc/*.hip, csrc/*.hpp and the public header."""
+    csrc = os.path.join(_PKG_ROOT, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.abspath(os.path.join(_PKG_ROOT, "..", "include", "gcn_uelb_hip.h")))
+    return files
+
+
+def source_hash():
+    """SHA-256 over the build flags and the names and contents of the library's sources.  build() stores it next
+    to the library (``<lib>.srchash``); load() refuses a library whose stored hash differs from the sources in the
+    tree, so new sources can never run against an old binary unnoticed (file times play no part)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(BUILD_FLAGS).encode())
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()
 
 
 class ModelDesc(ctypes.Structure):
@@ -61,6 +86,11 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = c_size_t
         fn.argtypes = [POINTER(ModelDesc)]
+    lib.gcn_model_saved_layout.restype = c_int
+    lib.gcn_model_saved_layout.argtypes = [POINTER(ModelDesc), c_int, POINTER(c_size_t)]
+    lib.gcn_bn_relu_pattern.restype = c_int
+    lib.gcn_bn_relu_pattern.argtypes = [c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]
     lib.gcn_model_fwd.restype = c_int
     lib.gcn_model_fwd.argtypes = [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -91,6 +121,8 @@ def _declare(lib):
         lib.gcn_load_factor.restype = c_int
         lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_layer_plan.restype = c_int
+    lib.gcn_layer_plan.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int)]
     lib.gcn_path_sample.restype = c_int
     lib.gcn_path_sample.argtypes = [c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -119,12 +151,28 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise GcnHipError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
                               f"(hipcc --offload-arch=gfx950); there is no fallback path")
+        stamp = LIB_PATH + ".srchash"
+        if os.path.exists(stamp) and os.path.isdir(os.path.join(_PKG_ROOT, "csrc")):
+            with open(stamp) as fh:
+                built_from = fh.read().strip()
+            if built_from != source_hash():
+                raise GcnHipError(f"{LIB_PATH} was built from other sources than those in {_PKG_ROOT}/csrc "
+                                  f"(stored hash {built_from[:12]}, tree {source_hash()[:12]}): rebuild it with "
+                                  f"`python __graft_entry__.py build`")
         lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
         if lib.gcn_abi_version() != ABI_VERSION:
             raise GcnHipError(f"ABI mismatch: library {lib.gcn_abi_version()} vs binding {ABI_VERSION}")
         _lib = lib
     return _lib
+
+
+def layer_plan(B, V, C, H):
+    """The library's launch plan for a problem size: dict with the row-chunk length of the edge backward pass
+    (``row_chunk``), chunks per graph, j tiles, edge-kernel grids and whether the wide kernels run."""
+    out = (c_int * 8)()
+    check(load().gcn_layer_plan(B, V, C, H, out), "gcn_layer_plan")
+    return dict(row_chunk=out[0], n_chunks=out[1], j_tiles=out[2], grid_fwd=out[3], grid_bwd=out[4], wide=bool(out[5]))
 
 
 def check(rc, what):

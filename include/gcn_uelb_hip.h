@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GCN_ABI_VERSION 2
+#define GCN_ABI_VERSION 3
 #define GCN_MAX_H 320
 #define GCN_LAYER_NPARAMS 12
 #define GCN_MAX_MLP_LAYERS 4
@@ -58,6 +58,11 @@ int gcn_prof_end(double* total_ms, int* launches);
  *   bn_node.batch_norm.weight, bn_node.batch_norm.bias, bn_edge.batch_norm.weight, bn_edge.batch_norm.bias
  * aggregation: 0 = "sum", 1 = "mean".  stream_id: distinguishes dropout streams (use the layer index).
  * ---------------------------------------------------------------------------------------------- */
+/* Launch plan the library picks for a problem size (introspection for tests and tools; nothing in the reference
+ * corresponds): out[0] = row-chunk length of the edge backward pass, out[1] = chunks per graph, out[2] = 16-row
+ * j tiles per (graph, row, commodity), out[3] / out[4] = workgroups of the forward / backward edge kernel,
+ * out[5] = 1 if the weight-streaming kernels (hidden_dim > 64) run, out[6], out[7] = 0. */
+int gcn_layer_plan(int B, int V, int C, int H, int out[8]);
 size_t gcn_layer_saved_floats(int B, int V, int C, int H);
 size_t gcn_layer_ws_bytes(int B, int V, int C, int H);
 
@@ -103,6 +108,17 @@ typedef struct gcn_model_desc {
 int gcn_model_num_params(const gcn_model_desc* d);
 size_t gcn_model_saved_floats(const gcn_model_desc* d);
 size_t gcn_model_ws_bytes(const gcn_model_desc* d);
+
+/* Test aids (nothing in the reference corresponds).  gcn_model_saved_layout: float offsets inside `saved` of
+ * what gcn_model_fwd keeps of layer `layer`: out[0] pre-BatchNorm edge activations e_tmp [B,V,V,C,H], out[1]
+ * pre-BatchNorm node activations x_tmp [B,V,C,H], out[2] BatchNorm statistics [4][H] (edge mean, edge 1/std,
+ * node mean, node 1/std), out[3] the layer's edge input, out[4] its node input; out[5..7] = 0.
+ * gcn_bn_relu_pattern: mask[row][h] = 1 iff the ReLU behind a BatchNorm is open at that element, decided with
+ * the expression the library's kernels use ((tmp - mean) * rstd * gamma + beta > 0 in float32), so that a
+ * reference can be given the library's own decision for BatchNorm outputs within rounding of zero. */
+int gcn_model_saved_layout(const gcn_model_desc* d, int layer, size_t out[8]);
+int gcn_bn_relu_pattern(size_t rows, int H, const float* tmp, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, unsigned char* mask, void* stream);
 
 /* y_pred: [B,V,V,C,voc_out].  loss_out[4] = {loss, sum of class weights, edge error %, 0}.
  * err_counts: int32 [2][B*C] (correct, mask) scratch owned by the caller (H <= 64 with mlp_layers <= 2 counts

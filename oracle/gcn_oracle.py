@@ -35,11 +35,16 @@ def batch_norm_rows(t: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) ->
     return (t - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
 
 
-def gcn_layer(x, e, P, prefix, aggregation="mean", dropout_p=0.0, training=False):
+def gcn_layer(x, e, P, prefix, aggregation="mean", dropout_p=0.0, training=False, relu_mask=None):
     """One ResidualGatedGCNLayer (src/gcn/models/gcn_layers.py:97-129).
 
     x: [B,V,C,H], e: [B,V,V,C,H].  Returns (x_new, e_new, aux) where aux holds the
     intermediates the HIP tests compare (e_tmp, gate sums, x_tmp).
+
+    relu_mask = (edge mask, node mask), 0/1 tensors of the shapes of e and x: the two ReLUs are replaced by a
+    product with the given pattern.  With the pattern relu itself would produce this changes nothing; tests pass
+    the pattern the HIP path decided on, so that BatchNorm outputs within float32 rounding of zero (which two
+    correct implementations may put on either side) take the same branch in both.
     """
     g = lambda n: P[prefix + n]
     # EdgeFeatures.forward, gcn_layers.py:81-94
@@ -60,9 +65,13 @@ def gcn_layer(x, e, P, prefix, aggregation="mean", dropout_p=0.0, training=False
     # BatchNorm, ReLU, residual, dropout: gcn_layers.py:122-128
     e_bn = batch_norm_rows(e_tmp, g("bn_edge.batch_norm.weight"), g("bn_edge.batch_norm.bias"))
     x_bn = batch_norm_rows(x_tmp, g("bn_node.batch_norm.weight"), g("bn_node.batch_norm.bias"))
-    e_new = F.dropout(F.relu(e_bn) + e, dropout_p, training)
-    x_new = F.dropout(F.relu(x_bn) + x, dropout_p, training)
-    return x_new, e_new, {"e_tmp": e_tmp, "x_tmp": x_tmp}
+    if relu_mask is None:
+        e_act, x_act = F.relu(e_bn), F.relu(x_bn)
+    else:
+        e_act, x_act = e_bn * relu_mask[0].to(e_bn.dtype), x_bn * relu_mask[1].to(x_bn.dtype)
+    e_new = F.dropout(e_act + e, dropout_p, training)
+    x_new = F.dropout(x_act + x, dropout_p, training)
+    return x_new, e_new, {"e_tmp": e_tmp, "x_tmp": x_tmp, "e_bn": e_bn, "x_bn": x_bn}
 
 
 def embed(P, x_edges_capacity, x_commodities, x_nodes):
@@ -113,7 +122,7 @@ def edge_error(y_pred, y_target):
 
 def model_forward(P, cfg, x_edges_capacity, x_commodities, x_nodes, y_edges=None, edge_cw=None,
                   compute_loss=True, mask_invalid_edges=False, training=False,
-                  layer_dropout=0.3, mlp_dropout=0.2, return_layers=False):
+                  layer_dropout=0.3, mlp_dropout=0.2, return_layers=False, relu_masks=None):
     """ResidualGatedGCNModel.forward (src/gcn/models/gcn_model.py:45-123).
 
     cfg: dict with num_layers, mlp_layers, aggregation, voc_edges_out.  The layer dropout is
@@ -123,7 +132,8 @@ def model_forward(P, cfg, x_edges_capacity, x_commodities, x_nodes, y_edges=None
     x, e = embed(P, x_edges_capacity, x_commodities, x_nodes)
     layers = []
     for l in range(cfg["num_layers"]):
-        x, e, aux = gcn_layer(x, e, P, f"gcn_layers.{l}.", cfg["aggregation"], layer_dropout, training)
+        x, e, aux = gcn_layer(x, e, P, f"gcn_layers.{l}.", cfg["aggregation"], layer_dropout, training,
+                              None if relu_masks is None else relu_masks[l])
         if return_layers:
             layers.append((x, e, aux))
     y = mlp(e, P, "mlp_edges.", cfg["mlp_layers"], mlp_dropout, training)
@@ -138,10 +148,68 @@ def model_forward(P, cfg, x_edges_capacity, x_commodities, x_nodes, y_edges=None
     if compute_loss:
         if y_edges is None or edge_cw is None:
             raise ValueError("y_edges and edge_cw required when compute_loss=True")
-        loss = loss_edges(y, y_edges, torch.as_tensor(edge_cw).to(y.dtype))
+        loss = loss_edges(y, y_edges, torch.as_tensor(edge_cw).to(device=y.device, dtype=y.dtype))
     if return_layers:
         return y, loss, layers
     return y, loss
+
+
+def model_loss_and_grads_checkpointed(P, cfg, x_edges_capacity, x_commodities, x_nodes, y_edges, edge_cw,
+                                      relu_masks=None, dy_pred=None):
+    """The same function as ``model_forward`` followed by ``loss.backward()`` (eval mode), arranged so that the
+    autograd graph of only one layer is alive at a time: the forward keeps each layer's inputs, the backward re-runs
+    one layer at a time under autograd and chains the gradients by hand.  For the large configurations (a float64
+    edge tensor of config 4 is 1.2 GB; the plain version keeps about seven of them per layer).
+
+    relu_masks: None, or a callable ``l -> (edge mask, node mask)`` (see ``gcn_layer``), called once in the forward
+    and once in the backward of layer l.  With ``y_edges`` None the scalar is sum(y * dy_pred) instead of the loss.
+    Returns (y, loss or None, grads) with grads keyed like P (zeros for parameters the result does not depend on).
+    """
+    L = cfg["num_layers"]
+    mask_of = (lambda l: None) if relu_masks is None else relu_masks
+    xs, es = [], []
+    with torch.no_grad():
+        x, e = embed(P, x_edges_capacity, x_commodities, x_nodes)
+        for l in range(L):
+            xs.append(x)
+            es.append(e)
+            x, e, _ = gcn_layer(x, e, P, f"gcn_layers.{l}.", cfg["aggregation"], relu_mask=mask_of(l))
+    grads = {k: torch.zeros_like(v) for k, v in P.items()}
+
+    def take(names, outs, ins, gouts):
+        params = [P[n] for n in names]
+        g = torch.autograd.grad(outs, ins + params, gouts, allow_unused=True)
+        for n, gv in zip(names, g[len(ins):]):
+            if gv is not None:
+                grads[n] = gv
+        return g[:len(ins)]
+
+    # head
+    eL = e.detach().requires_grad_(True)
+    y = mlp(eL, P, "mlp_edges.", cfg["mlp_layers"])
+    if cfg["voc_edges_out"] == 1:
+        y = y.squeeze(-1)
+    loss = None
+    if y_edges is not None:
+        loss = loss_edges(y, y_edges, torch.as_tensor(edge_cw).to(device=y.device, dtype=y.dtype))
+        scalar = loss
+    else:
+        scalar = (y * dy_pred).sum()
+    (de,) = take([k for k in P if k.startswith("mlp_edges.")], [scalar], [eL], None)
+    y, loss = y.detach(), (None if loss is None else loss.detach())
+    dx = None
+    del eL, e, x
+    for l in reversed(range(L)):
+        xi, ei = xs.pop().requires_grad_(True), es.pop().requires_grad_(True)
+        xo, eo, _ = gcn_layer(xi, ei, P, f"gcn_layers.{l}.", cfg["aggregation"], relu_mask=mask_of(l))
+        outs, gouts = ([eo], [de]) if dx is None else ([xo, eo], [dx, de])
+        dx, de = take([k for k in P if k.startswith(f"gcn_layers.{l}.")], outs, [xi, ei], gouts)
+        if dx is None:
+            dx = torch.zeros_like(xi)
+        del xi, ei, xo, eo
+    x0, e0 = embed(P, x_edges_capacity, x_commodities, x_nodes)
+    take(["nodes_embedding.weight", "commodities_embedding.weight", "edges_values_embedding.weight"], [x0, e0], [], [dx, de])
+    return y, loss, grads
 
 
 def beam_scores(y_pred_edges):

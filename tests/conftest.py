@@ -30,3 +30,15 @@ def load_golden(path):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def report(line):
+    """Append a line to gpurun_out/test_report.log (numbers worth keeping from passing tests: worst errors, tie counts).
+    Long tests call it once per stage, which also shows progress to whoever watches the directory."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_report.log"), "a") as fh:
+            fh.write(line.rstrip("\n") + "\n")
+    except OSError:
+        pass

@@ -41,6 +41,27 @@ def test_size_queries_and_argument_errors_without_gpu():
     assert lib.gcn_model_num_params(ctypes.byref(d)) == 3 + 12 * 2 + 4
 
 
+def test_plan_and_saved_layout_queries_without_gpu():
+    from src.gcn.hip import lib as L
+    lib = L.load()
+    plan = L.layer_plan(20, 14, 10, 64)
+    assert plan["j_tiles"] == 1 and not plan["wide"] and 1 <= plan["row_chunk"] <= 14
+    assert plan["n_chunks"] == -(-14 // plan["row_chunk"]) and plan["grid_fwd"] > 0 and plan["grid_bwd"] > 0
+    assert L.layer_plan(1, 100, 50, 300)["wide"]
+    d = L.ModelDesc(B=2, V=5, C=3, H=8, L=3, mlp_layers=2, voc_out=2, n_emb=9, aggregation=1)
+    total = lib.gcn_model_saved_floats(ctypes.byref(d))
+    Re, Rn, H = 2 * 5 * 5 * 3, 2 * 5 * 3, 8
+    seen = set()
+    for layer in range(3):
+        off = (ctypes.c_size_t * 8)()
+        assert lib.gcn_model_saved_layout(ctypes.byref(d), layer, off) == 0
+        spans = [(off[0], Re * H), (off[1], Rn * H), (off[2], 4 * H), (off[3], Re * H), (off[4], Rn * H)]
+        for lo, n in spans:
+            assert lo + n <= total and lo not in seen       # inside the buffer, no two tensors at one offset
+            seen.add(lo)
+    assert lib.gcn_model_saved_layout(ctypes.byref(d), 3, off) != 0 and b"layer" in lib.gcn_last_error()
+
+
 class _Cfg(dict):
     __getattr__ = dict.__getitem__
 

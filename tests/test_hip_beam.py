@@ -154,3 +154,38 @@ def test_beam_tight_capacities_match_c_oracle(algo, V, C, K, B, seed):
     assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
     if algo in ("standard", "greedy"):
         assert int(a.attempts.sum()) == used
+
+
+@pytest.mark.parametrize("algo,cap_lo,cap_hi", [("deterministic", 1000, 5000), ("standard", 1000, 5000), ("deterministic", 300, 1500)])
+def test_beam_at_200_nodes_100_commodities_matches_c_oracle(algo, cap_lo, cap_hi):
+    """The largest BASELINE configuration (V = 200, C = 100, K = 10, strict): 160 KB capacity matrices live in the
+    workspace instead of LDS, paths of up to 200 nodes, 100 sequentially dependent commodities per graph.  Scores
+    favour each commodity's labelled path (as a trained model's would) with random decoys tied with the label edges,
+    so that some graphs decode completely and others run into retries and the fallback; bit-exact against the
+    sequential C oracle."""
+    from src.common.synthetic import make_batch
+    dev = _dev()
+    B, V, C, K, max_iter = 2, 200, 100, 10, 5
+    b = make_batch(B, V, C, "random", cap_lo, cap_hi, 5, 500, seed=300)
+    rng = np.random.default_rng(V * 100 + C)
+    p = rng.random((B, V, V, C)).astype(np.float32) * 0.3 + 0.01
+    p[b["edges_target"] == 1] = 0.9
+    p[rng.random(p.shape) < 0.02] = 0.9
+    y = np.log(p).astype(np.float32)
+    perms = np.stack([rng.permutation(C) for _ in range(B * max_iter)]).astype(np.int32)
+    rp, rl, rf, ratt, used = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, algo, True, max_iter, perms)
+    a = _make(algo, y, b["edges_capacity"], b["commodities"], K, True, max_iter, dev)
+    it = iter([torch.from_numpy(q.astype(np.int64)) for q in perms])
+    orig = torch.randperm
+    torch.randperm = lambda n, *args, **kw: next(it, torch.arange(n))
+    try:
+        a.search()
+    finally:
+        torch.randperm = orig
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+    if algo == "standard":
+        assert int(a.attempts.sum()) == used
+    if cap_lo == 1000:
+        assert rf.max() == 1 and rl.max() > 10          # at least one graph decoded completely, with long paths

@@ -1,104 +1,247 @@
-"""GPU parity at the full sizes of the shipped configurations (B = 20 graphs, all L = 10 layers) and on a
-large ragged shape, against the CPU oracle on the same seeded synthetic batch.
+"""GPU parity at the full sizes of the BASELINE configurations, against the oracle in float64 on the same seeded
+synthetic batch, every value held to the 1e-4 bound:
 
-The oracle runs in float64 here: at these sizes the float32 CPU oracle is itself up to 2e-4 (relative to the
-largest entry) away from the float64 result in some weight gradients (sums over 39,200+ rows with heavy
-cancellation), i.e. beyond the 1e-4 bound it is supposed to pin, while the HIP path stays within ~1e-5 of float64.
+  * the three shipped configurations at B = 20 graphs and all L = 10 layers,
+  * the two large synthetic ones at one graph per GPU with ALL their layers: 100 nodes x 50 commodities at H = 300,
+    L = 30, and 200 nodes x 100 commodities at H = 64, L = 10.
 
-Forward results (logits, loss, edge error) are held to the 1e-4 relative bound.  Gradients after ten layers
-are compared with a bound that tolerates ReLU ties: among ~25 million BatchNorm outputs per configuration a
-handful fall within fp32 rounding of zero and may legitimately land on either side in two correct
-implementations, which moves individual gradient entries by a whole element's contribution.  So at least
-99.9 % of every gradient tensor's entries must meet the 1e-4 bound and none may be off by more than 2 % of
-the tensor's largest entry.
+The oracle runs in float64 on the GPU (plain PyTorch, the same code that the golden vectors pin on the CPU), layer by
+layer with one layer's autograd graph alive at a time (``model_loss_and_grads_checkpointed``), which is what lets all
+30 layers of the H = 300 configuration fit.
+
+ReLU ties.  Among the 10^7..10^9 BatchNorm outputs of a configuration a few fall within float32 rounding of zero;
+two correct implementations may put such an element on either side of the ReLU, and the gradient then differs by
+that element's whole contribution.  The tests do not tolerate that away: the oracle is given the ReLU pattern the
+HIP path actually used (read back with gcn_bn_relu_pattern from the activations the forward pass saved), and every
+gradient entry must then meet the bound.  That the handed-over pattern differs from the oracle's own only at ties is
+checked too: wherever the two disagree, the oracle's BatchNorm output must be zero at the parity tolerance (below 1e-4 of the tensor's largest output).
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import gcn_oracle
-from test_hip_parity import RTOL, _Cfg, _dev, assert_close
+from conftest import report
+from test_hip_parity import RTOL, _Cfg, _dev
 
 pytestmark = pytest.mark.gpu
 
 
-def assert_grad_close(got, ref, what, floor, frac=1e-3, rtol=RTOL):
-    got = got.detach().double().cpu()
-    ref = ref.detach().double().cpu()
-    scale = max(float(ref.abs().max()), floor)
-    err = (got - ref).abs()
-    bad = float((err > rtol * scale).double().mean())
-    assert bad <= frac, f"{what}: {bad:.2e} of the entries exceed {rtol:g} x {scale:.3e}"
-    assert float(err.max()) <= 2e-2 * scale, f"{what}: max err {float(err.max()):.3e} vs scale {scale:.3e}"
+def _rel_err(got, ref):
+    """max |got - ref| / max |ref| on the device, in float64."""
+    ref = ref.double()
+    return float((got.double() - ref).abs().max()), float(ref.abs().max())
 
 
-@pytest.mark.parametrize("name", ["nsfnet_10_commodities", "nsfnet_20_commodities", "default2"])
-def test_full_config_forward_backward(name):
+class _HipRun:
+    """One eager forward + backward of the model through HipTrainStep, plus access to what the forward saved."""
+
+    def __init__(self, model, batch, dev, B):
+        from src.gcn.hip import lib as L
+        from src.gcn.hip.train_step import HipTrainStep
+        self.L = L
+        self.lib = L.load()
+        self.model = model
+        self.step = HipTrainStep(model, B, dev, use_graph=False)
+        self.step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
+                             batch["edges_target"], batch["edge_cw"])
+        self.dev = dev
+
+    def run(self):
+        out = self.step.step()
+        torch.cuda.synchronize()
+        return out
+
+    def relu_masks(self, l):
+        """(edge mask [B,V,V,C,H], node mask [B,V,C,H]) uint8: the ReLU decisions of layer l's two BatchNorms."""
+        L, st = self.L, self.step
+        off = (ctypes.c_size_t * 8)()
+        L.check(self.lib.gcn_model_saved_layout(ctypes.byref(st.desc), l, off), "gcn_model_saved_layout")
+        B, V, C, H = st.B, st.V, st.C, self.model.hidden_dim
+        Re, Rn = B * V * V * C, B * V * C
+        saved = st.saved
+        stats = saved[off[2]:off[2] + 4 * H]
+        lp = self.model.gcn_layers[l]
+        out = []
+        for rows, o_tmp, s0, bn in ((Re, off[0], 0, lp.bn_edge.batch_norm), (Rn, off[1], 2, lp.bn_node.batch_norm)):
+            mask = torch.empty(rows * H, dtype=torch.uint8, device=self.dev)
+            tmp = saved[o_tmp:o_tmp + rows * H]
+            rc = self.lib.gcn_bn_relu_pattern(rows, H, L.ptr(tmp), L.ptr(stats[s0 * H:]), L.ptr(stats[(s0 + 1) * H:]),
+                                              L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(mask),
+                                              L.stream_ptr(self.dev))
+            L.check(rc, "gcn_bn_relu_pattern")
+            out.append(mask)
+        return out[0].view(B, V, V, C, H), out[1].view(B, V, C, H)
+
+
+def _check_config(name, B, seed=99, init_seed=5):
     from src.common.synthetic import CONFIGS, make_batch
     from src.gcn.models.gcn_model import ResidualGatedGCNModel
     dev = _dev()
     s = CONFIGS[name]
-    B, V, C, H, L = s["B"], s["V"], s["C"], s["H"], s["L"]
-    batch = make_batch(B, V, C, s["topology"], s["cap_lo"], s["cap_hi"], s["dem_lo"], s["dem_hi"], seed=99)
-    cfg = _Cfg(num_nodes=V, num_commodities=C, voc_edges_in=3, voc_edges_out=2, hidden_dim=H, num_layers=L,
+    V, C, H, Lr = s["V"], s["C"], s["H"], s["L"]
+    batch = make_batch(B, V, C, s["topology"], s["cap_lo"], s["cap_hi"], s["dem_lo"], s["dem_hi"], seed=seed)
+    cfg = _Cfg(num_nodes=V, num_commodities=C, voc_edges_in=3, voc_edges_out=2, hidden_dim=H, num_layers=Lr,
                mlp_layers=2, aggregation="mean")
-    torch.manual_seed(5)
-    model = ResidualGatedGCNModel(cfg, torch.float32, torch.long)
-    P = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.state_dict().items()}
-    cap = torch.from_numpy(batch["edges_capacity"])
-    comm = torch.from_numpy(batch["commodities"])
-    nodes = torch.from_numpy(batch["nodes"])
-    y_edges = torch.from_numpy(batch["edges_target"])
-    cw = batch["edge_cw"]
-    ocfg = dict(num_layers=L, mlp_layers=2, aggregation="mean", voc_edges_out=2)
-    y_ref, loss_ref = gcn_oracle.model_forward(P, ocfg, cap.double(), comm[:, :, 2].double(), nodes, y_edges, cw)
-    loss_ref.backward()
-    err_ref, _ = gcn_oracle.edge_error(y_ref.detach(), y_edges)
-    model = model.to(dev).eval()          # dropout off, BatchNorm on batch statistics as always
-    x_edges = (cap > 0).long().to(dev)
-    y, loss = model(x_edges, comm.to(dev), cap.to(dev), nodes.to(dev), y_edges.to(dev), cw)
-    loss.backward()
-    assert_close(y, y_ref, "y_pred")
-    assert_close(loss, loss_ref, "loss")
-    assert_close(model.last_edge_error, float(err_ref), "edge_error")
-    # parameters the loss does not depend on (node side of the last layer) have no gradient in the oracle and zeros here
-    ref = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}
-    gmax = max(float(g.abs().max()) for g in ref.values())
-    for k, p in model.named_parameters():
-        assert_grad_close(p.grad, ref[k], "grad " + k, floor=1e-6 * gmax)
+    torch.manual_seed(init_seed)
+    model = ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(dev).eval()   # dropout off, BatchNorm on batch statistics
+    hip = _HipRun(model, batch, dev, B)
+    out = hip.run()
+    loss, err = float(out[0]), float(out[2])
+
+    P = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    t = lambda a: torch.from_numpy(a).to(dev)
+    cap, comm, nodes, y_edges = t(batch["edges_capacity"]), t(batch["commodities"]), t(batch["nodes"]), t(batch["edges_target"])
+    ocfg = dict(num_layers=Lr, mlp_layers=2, aggregation="mean", voc_edges_out=2)
+
+    # (1) the handed-over pattern differs from the oracle's own ReLU decisions only where the BatchNorm output is a tie
+    ties, worst_tie = [0, 0], 0.0
+    with torch.no_grad():
+        x, e = gcn_oracle.embed(P, cap.double(), comm[:, :, 2].double(), nodes)
+        for l in range(Lr):
+            me, mx = hip.relu_masks(l)
+            x, e, aux = gcn_oracle.gcn_layer(x, e, P, f"gcn_layers.{l}.", "mean", relu_mask=(me, mx))
+            for k, (bn, m) in enumerate(((aux["e_bn"], me), (aux["x_bn"], mx))):
+                differ = (bn > 0) != m.bool()
+                n = int(differ.sum())
+                ties[k] += n
+                if n:
+                    # "a tie" = zero at the parity tolerance: below 1e-4 of the largest BatchNorm output of the tensor
+                    worst, top = float(bn[differ].abs().max()), float(bn.abs().max())
+                    worst_tie = max(worst_tie, worst / top)
+                    assert worst <= RTOL * top, f"layer {l}: ReLU pattern differs at a BatchNorm output of {worst:.3e} (largest {top:.3e})"
+            del aux, me, mx
+        del x, e
+    # (2) with that pattern, everything within 1e-4
+    y_ref, loss_ref, gref = gcn_oracle.model_loss_and_grads_checkpointed(
+        P, ocfg, cap.double(), comm[:, :, 2].double(), nodes, y_edges, batch["edge_cw"], relu_masks=hip.relu_masks)
+    errv, scale = _rel_err(hip.step.y_pred, y_ref)
+    assert errv <= RTOL * scale, f"y_pred: max err {errv:.3e} vs scale {scale:.3e}"
+    assert abs(loss - float(loss_ref)) <= RTOL * abs(float(loss_ref))
+    err_ref, _ = gcn_oracle.edge_error(y_ref, y_edges)
+    assert abs(err - float(err_ref)) <= RTOL * max(abs(float(err_ref)), 1.0)
+    gmax = max(float(g.abs().max()) for g in gref.values())
+    worst = []
+    for (k, p), g in zip(model.named_parameters(), hip.step.grad_views):
+        errv, scale = _rel_err(g, gref[k])
+        worst.append((errv / max(scale, 1e-6 * gmax), k, errv, scale))
+    worst.sort(reverse=True)
+    yerr, yscale = _rel_err(hip.step.y_pred, y_ref)
+    report(f"[fullsize {name}] B={B} L={Lr}: loss {loss:.6f} (oracle {float(loss_ref):.6f}); y_pred err {yerr / yscale:.2e}; "
+           f"ReLU decisions that differ from the float64 oracle's, edge/node: {ties} (largest |BN| among them "
+           f"{worst_tie:.1e} of the tensor's maximum); worst gradient tensors, err / max(scale, floor): "
+           + ", ".join(f"{k} {r:.2e}" for r, k, _, _ in worst[:3]))
+    for r, k, errv, scale in worst:
+        # gradients that are zero in exact arithmetic (biases in front of a BatchNorm, the node branch of the last
+        # layer) get an absolute floor of 1e-6 x the largest gradient of the model
+        assert errv <= RTOL * scale + 1e-6 * gmax, f"grad {k}: max err {errv:.3e} vs scale {scale:.3e} (every entry, no tolerated fraction)"
+    return hip, batch
+
+
+@pytest.mark.parametrize("name", ["nsfnet_10_commodities", "nsfnet_20_commodities", "default2"])
+def test_full_config_forward_backward(name):
+    from src.common.synthetic import CONFIGS
+    _check_config(name, CONFIGS[name]["B"])
+
+
+def test_config4_100_nodes_50_commodities_h300_all_30_layers():
+    """BASELINE config 4 on its own workload: V = 100, C = 50, H = 300, L = 30 (all layers), one graph per GPU:
+    500,000 edge rows, a 600 MB edge tensor per layer in float32."""
+    hip, _ = _check_config("synthetic_100n_50c_h300_l30", 1)
+    _train_mode_properties(hip)
+
+
+def test_config5_200_nodes_100_commodities_all_layers():
+    """BASELINE config 5 on its own workload: V = 200, C = 100, H = 64, L = 10, one graph per GPU: 4,000,000 edge
+    rows, a 1 GB edge tensor per layer."""
+    hip, _ = _check_config("synthetic_200n_100c", 1)
+    _train_mode_properties(hip)
+
+
+def _train_mode_properties(hip):
+    """Dropout on, at full depth: finite loss and gradients, new masks on every step (the loss moves), gradients of
+    two steps differ, and eval mode afterwards reproduces the eval result bit for bit."""
+    st, model = hip.step, hip.model
+    eval_loss = float(st.loss_out[0])
+    eval_grad = st.flat_grad.clone()
+    model.train()
+    losses, grads = [], []
+    for _ in range(2):
+        out = st.step()
+        torch.cuda.synchronize()
+        losses.append(float(out[0]))
+        assert bool(torch.isfinite(st.flat_grad).all())
+        grads.append(st.flat_grad.clone())
+    assert all(np.isfinite(v) for v in losses) and losses[0] != losses[1]
+    assert not torch.equal(grads[0], grads[1])
+    model.eval()
+    out = st.step()
+    torch.cuda.synchronize()
+    assert float(out[0]) == eval_loss and torch.equal(st.flat_grad, eval_grad)
 
 
 def test_layer_large_ragged_shape():
-    """One layer at V = 200 nodes (13 row tiles per node, the last one half full), 25 commodities: a quarter of
-    the 200-node / 100-commodity synthetic configuration per graph (1 M edge rows)."""
+    """One layer at V = 200 nodes (13 row tiles per node, the last one half full), 25 commodities, through the
+    stand-alone layer entry points gcn_layer_fwd / gcn_layer_bwd called directly (explicit BatchNorm-apply launches,
+    their own statistics passes), against the float64 oracle given the ReLU pattern of the HIP run (read from the
+    `saved` buffer: pre-BatchNorm edge rows first, then the node rows, statistics last)."""
+    from src.gcn.hip import lib as L
     from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
-    from test_hip_parity import _relu_margin
     dev = _dev()
+    lib = L.load()
     B, V, C, H = 1, 200, 25, 64
+    Re, Rn = B * V * V * C, B * V * C
     torch.manual_seed(11)
-    layer = ResidualGatedGCNLayer(H, "mean").eval()
-    x = torch.randn(B, V, C, H)
-    e = torch.randn(B, V, V, C, H) * 2.0
-    gx, ge = torch.randn(B, V, C, H), torch.randn(B, V, V, C, H)
-    P = {k: v.detach().clone().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    layer = ResidualGatedGCNLayer(H, "mean").to(dev).eval()
+    x = torch.randn(B, V, C, H, device=dev)
+    e = torch.randn(B, V, V, C, H, device=dev) * 2.0
+    gx, ge = torch.randn(B, V, C, H, device=dev), torch.randn(B, V, V, C, H, device=dev)
+    params = [p.detach().contiguous() for p in layer.hip_parameters()]
+    saved = torch.empty(lib.gcn_layer_saved_floats(B, V, C, H), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.gcn_layer_ws_bytes(B, V, C, H), dtype=torch.uint8, device=dev)
+    x2, e2 = torch.empty_like(x), torch.empty_like(e)
+    st = L.stream_ptr(dev)
+    L.check(lib.gcn_layer_fwd(B, V, C, H, 1, 0.0, 0, None, 0, L.ptr(x), L.ptr(e), L.ptr_array(params), L.ptr(x2), L.ptr(e2),
+                              L.ptr(saved), L.ptr(ws), ws.numel(), st), "gcn_layer_fwd")
+    dx, de = gx.clone(), ge.clone()
+    grads = [torch.empty_like(p) for p in params]
+    L.check(lib.gcn_layer_bwd(B, V, C, H, 1, 0.0, 0, None, 0, L.ptr(x), L.ptr(e), L.ptr_array(params), L.ptr(saved), L.ptr(dx),
+                              L.ptr(de), L.ptr_array(grads), L.ptr(ws), ws.numel(), st), "gcn_layer_bwd")
+    stats = saved[Re * H + 4 * Rn * H:]
+    masks = []
+    for rows, tmp, s0, bn in ((Re, saved[:Re * H], 0, layer.bn_edge.batch_norm), (Rn, saved[Re * H:Re * H + Rn * H], 2, layer.bn_node.batch_norm)):
+        m = torch.empty(rows * H, dtype=torch.uint8, device=dev)
+        L.check(lib.gcn_bn_relu_pattern(rows, H, L.ptr(tmp), L.ptr(stats[s0 * H:]), L.ptr(stats[(s0 + 1) * H:]),
+                                        L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(m), st), "gcn_bn_relu_pattern")
+        masks.append(m)
+    me, mx = masks[0].view(B, V, V, C, H), masks[1].view(B, V, C, H)
+    torch.cuda.synchronize()
+    P = {k: v.detach().double().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
     xo, eo = x.double().requires_grad_(True), e.double().requires_grad_(True)
-    x1, e1, _ = gcn_oracle.gcn_layer(xo, eo, P, "", "mean")
+    x1, e1, aux = gcn_oracle.gcn_layer(xo, eo, P, "", "mean", relu_mask=(me, mx))
+    ties = []
+    for bn, m in ((aux["e_bn"], me), (aux["x_bn"], mx)):
+        differ = (bn.detach() > 0) != m.bool()
+        ties.append(int(differ.sum()))
+        if ties[-1]:
+            assert float(bn.detach()[differ].abs().max()) <= RTOL * float(bn.detach().abs().max())
     ((x1 * gx.double()).sum() + (e1 * ge.double()).sum()).backward()
-    layer = layer.to(dev)
-    xh, eh = x.to(dev).requires_grad_(True), e.to(dev).requires_grad_(True)
-    x2, e2 = layer(xh, eh)
-    ((x2 * gx.to(dev)).sum() + (e2 * ge.to(dev)).sum()).backward()
-    assert_close(x2, x1, "x_new")
-    assert_close(e2, e1, "e_new")
+    worst = []
+    for got, ref, what in ((x2, x1, "x_new"), (e2, e1, "e_new"), (dx, xo.grad, "dx_in"), (de, eo.grad, "de_in")):
+        errv, scale = _rel_err(got.detach(), ref.detach())
+        worst.append(f"{what} {errv / scale:.2e}")
+        assert errv <= RTOL * scale, f"{what}: max err {errv:.3e} vs scale {scale:.3e}"
     gmax = max(float(P[k].grad.abs().max()) for k in P)
-    # one ReLU tie among the 64 M edge BatchNorm outputs moves two whole rows of dx_in (128 of its 320,000 entries)
-    assert_grad_close(xh.grad, xo.grad, "dx_in", 0.0, frac=1e-2)
-    assert_grad_close(eh.grad, eo.grad, "de_in", 0.0)
-    for k, p in layer.named_parameters():
-        # biases in front of a BatchNorm have zero gradient in exact arithmetic; over 1 M rows the float32 sums
-        # that cancel to it leave noise of a few 1e-6 of the largest gradient, so those are only held to 1e-5 of it
+    for (k, _), g in zip(layer.named_parameters(), grads):
+        errv, scale = _rel_err(g, P[k].grad)
+        # the four Linear biases sit in front of a BatchNorm (or, for node_feat.V, a gate-weighted mean that feeds one):
+        # their gradient is a sum over 10^6 rows of terms of order one that cancels to exactly zero, and what any
+        # float32 implementation returns is the rounding noise of that sum (6e-3 here, 6e-9 of the sum of magnitudes);
+        # those four are held to 1e-5 of the largest gradient instead of 1e-6
         zero_exact = k.endswith(".bias") and "batch_norm" not in k
-        # weight gradients here are float32 sums over 1 M rows (products accumulated in float32 within each of
-        # 256 row slices, slices added in float64): rounding alone reaches a few 1e-4 of the largest entry, as it
-        # does in the float32 reference, so the bound for them is 1e-3
-        assert_grad_close(p.grad, P[k].grad, "grad " + k, floor=(0.1 if zero_exact else 1e-6) * gmax, rtol=1e-3)
+        floor = (1e-5 if zero_exact else 1e-6) * gmax
+        worst.append(f"{k} {errv / max(scale, floor):.2e}")
+        assert errv <= RTOL * scale + floor, f"grad {k}: max err {errv:.3e} vs scale {scale:.3e}"
+    report(f"[fullsize layer V=200 C=25] ReLU decisions differing from the float64 oracle's, edge/node: {ties}; errors: " + ", ".join(worst))

@@ -131,18 +131,20 @@ def test_model_matches_reference_golden(path):
         assert_close(p.grad, g["grad." + k], "grad " + k, atol=1e-6 * gmax)
 
 
-@pytest.mark.parametrize("B,V,C,H,it", [(3, 14, 4, 64, 0), (1, 35, 2, 96, 4), (1, 20, 2, 304, 20)])
-def test_layer_train_mode_dropout_semantics(monkeypatch, B, V, C, H, it):
+@pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (1, 35, 15, 96, 2), (2, 4, 512, 304, 4)])
+def test_layer_train_mode_dropout_semantics(B, V, C, H, chunk):
     """Train-mode outputs cannot match the reference bit for bit (different RNG).  Check instead that
     (1) ~(1-p) of the elements survive, (2) the output equals the oracle's pre-dropout output times
     mask/(1-p) with the mask read off the HIP output, i.e. dropout acts on relu(BN)+residual as in
     gcn_layers.py:124-128, (3) backward regenerates the same mask (gradients equal the oracle's with that
     mask), (4) the mask changes from call to call, and eval mode is deterministic.  The cases above 64 channels walk
-    several column tiles and several rows per step (it = row-chunk length override, 0 = the library's choice)."""
+    several column tiles and several rows per step (chunk = the row-chunk length the library picks for that size,
+    checked through gcn_layer_plan; 0 = not checked)."""
+    from src.gcn.hip import lib as L
     from src.gcn.models.gcn_layers import ResidualGatedGCNLayer
     dev = _dev()
-    if it:
-        monkeypatch.setenv("GCN_TUNE_IT", str(it))
+    if chunk:
+        assert L.layer_plan(B, V, C, H)["row_chunk"] == chunk
     p = 0.3
     for seed in range(64):
         torch.manual_seed(seed)
@@ -204,12 +206,20 @@ def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
     test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
 
 
-@pytest.mark.parametrize("it", [2, 3, 7, 40])
-@pytest.mark.parametrize("B,V,C,H,agg", [(1, 18, 2, 128, "mean"), (1, 40, 1, 80, "sum")])
-def test_wide_layer_row_chunks(monkeypatch, it, B, V, C, H, agg):
-    """The backward edge kernel walks the rows i of a chunk three at a time: chunk lengths that leave one, two or no
-    rows over, and one chunk for the whole graph (the library reads the chunk length override on every call)."""
-    monkeypatch.setenv("GCN_TUNE_IT", str(it))
+@pytest.mark.parametrize("B,V,C,H,agg,chunk,nchunks", [
+    (1, 18, 44, 128, "mean", 2, 9),      # chunks of two rows: every three-row step has one row missing
+    (1, 18, 72, 128, "sum", 3, 6),       # whole steps only
+    (1, 19, 110, 80, "mean", 6, 4),      # 6 + 6 + 6 + 1 rows
+    (1, 40, 40, 80, "sum", 6, 7),        # six chunks of 6 and one of 4 = 3 + 1, three j tiles
+    (4, 7, 256, 80, "mean", 7, 1),       # one chunk for the whole graph: 3 + 3 + 1
+])
+def test_wide_layer_row_chunks(B, V, C, H, agg, chunk, nchunks):
+    """The backward edge kernel walks the rows i of a chunk three at a time: problem sizes for which the library picks
+    chunk lengths that leave one, two or no rows over, and one chunk for the whole graph.  The plan is read back
+    through gcn_layer_plan, so a change of the library's choice shows up here instead of silently dropping a case."""
+    from src.gcn.hip import lib as L
+    plan = L.layer_plan(B, V, C, H)
+    assert plan["wide"] and (plan["row_chunk"], plan["n_chunks"]) == (chunk, nchunks), plan
     test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
 
 
