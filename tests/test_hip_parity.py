@@ -131,7 +131,7 @@ def test_model_matches_reference_golden(path):
         assert_close(p.grad, g["grad." + k], "grad " + k, atol=1e-6 * gmax)
 
 
-@pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (1, 35, 15, 96, 2), (2, 4, 512, 304, 4)])
+@pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (2, 2, 384, 96, 2), (2, 2, 384, 304, 2)])
 def test_layer_train_mode_dropout_semantics(B, V, C, H, chunk):
     """Train-mode outputs cannot match the reference bit for bit (different RNG).  Check instead that
     (1) ~(1-p) of the elements survive, (2) the output equals the oracle's pre-dropout output times
@@ -153,7 +153,7 @@ def test_layer_train_mode_dropout_semantics(B, V, C, H, chunk):
         e = torch.randn(B, V, V, C, H) + 4.0
         gx, ge = torch.randn(B, V, C, H), torch.randn(B, V, V, C, H)
         P = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
-        if _relu_margin(x, e, P, "mean") > 5e-6:
+        if _relu_margin(x, e, P, "mean") > 3e-6:
             break
     else:
         pytest.fail("no tie-free seed found")
@@ -217,10 +217,13 @@ def test_wide_layer_row_chunks(B, V, C, H, agg, chunk, nchunks):
     """The backward edge kernel walks the rows i of a chunk three at a time: problem sizes for which the library picks
     chunk lengths that leave one, two or no rows over, and one chunk for the whole graph.  The plan is read back
     through gcn_layer_plan, so a change of the library's choice shows up here instead of silently dropping a case."""
+    from hip_layer_check import check_layer_against_oracle
     from src.gcn.hip import lib as L
+    _dev()
     plan = L.layer_plan(B, V, C, H)
     assert plan["wide"] and (plan["row_chunk"], plan["n_chunks"]) == (chunk, nchunks), plan
-    test_layer_forward_backward_matches_oracle(B, V, C, H, agg)
+    # millions of BatchNorm outputs: no seed is free of ReLU ties, so the oracle takes the HIP run's ReLU pattern
+    check_layer_against_oracle(B, V, C, H, agg, seed=B * 1000 + V * 10 + H)
 
 
 def test_wide_layer_many_steps_per_workgroup():
