@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -1364,6 +1365,46 @@ int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* pa
     k_max_load_factor<<<B, 256, 0, st>>>(V, usage_ws, cap, max_lf);
     GCN_CHECK_LAUNCH("k_max_load_factor");
     return 0;
+}
+
+// ---- load factor without any allocation: the usage scratch is a fixed array of the code object ----------
+// In host code the array's name is only a handle for hipGetSymbolAddress; every use of its memory goes through the
+// per-device address looked up once per device (each GPU holds its own copy at its own address).
+static __device__ __align__(256) int scratch[GCN_STATIC_USAGE_INTS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+int* g_scratch_ptr[kMaxDevices] = {};
+
+int static_scratch(int** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return fail(-3, "gcn_load_factor_static: no current device");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr)
+            return fail(-3, "gcn_load_factor_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<int*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+int gcn_load_factor_static(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
+                           const long long* comm, float* max_lf, unsigned char* complete, void* stream) {
+    if (B <= 0 || V <= 0 || C <= 0 || PL <= 0) return fail(-1, "gcn_load_factor_static: non-positive dimension");
+    if (!paths || !path_len || !cap || !comm || !max_lf || !complete) return fail(-1, "gcn_load_factor_static: null pointer argument");
+    const size_t n = (size_t)B * V * V;
+    if (n > (size_t)GCN_STATIC_USAGE_INTS)
+        return fail(-2, "gcn_load_factor_static: B*V*V = %zu exceeds the static scratch of %u int32 (use gcn_load_factor with a caller buffer)",
+                    n, (unsigned)GCN_STATIC_USAGE_INTS);
+    int* usage = nullptr;
+    if (int rc = static_scratch(&usage)) return rc;
+    // the array keeps the previous call's counts: gcn_load_factor clears the part this call uses
+    return gcn_load_factor(B, V, C, PL, paths, path_len, cap, comm, usage, max_lf, complete, stream);
 }
 
 namespace {

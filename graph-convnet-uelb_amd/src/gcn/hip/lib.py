@@ -121,6 +121,9 @@ def _declare(lib):
         lib.gcn_load_factor.restype = c_int
         lib.gcn_load_factor.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.gcn_load_factor_static.restype = c_int
+    lib.gcn_load_factor_static.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]
     lib.gcn_layer_plan.restype = c_int
     lib.gcn_layer_plan.argtypes = [c_int, c_int, c_int, c_int, POINTER(c_int)]
     lib.gcn_path_sample.restype = c_int

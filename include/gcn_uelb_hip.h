@@ -191,6 +191,18 @@ int gcn_beam_scores(int B, int V, int C, int five_d, const float* in, float* y, 
 int gcn_load_factor(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
                     const long long* comm, int* usage_ws, float* max_lf, unsigned char* complete, void* stream);
 
+/* The same computation for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The B*V*V int32 usage
+ * scratch that gcn_load_factor takes from the caller lives in a fixed array inside the library's code object
+ * (GCN_STATIC_USAGE_INTS int32 = 4 MiB, held by every GPU the library runs on until the process ends); the call
+ * makes no hipMalloc / hipFree and no other allocating call.  B*V*V > GCN_STATIC_USAGE_INTS is refused (-2).
+ * Every call on one GPU shares that GPU's array (it is cleared at the start of each call, on `stream`): calls
+ * that overlap on one GPU (different streams or host threads) race; stream-ordered calls are fine.  The first
+ * call on a device looks up the array's device address (hipGetSymbolAddress); make it outside stream capture. */
+#define GCN_STATIC_USAGE_INTS (1u << 20)
+int gcn_load_factor_static(int B, int V, int C, int PL, const int* paths, const int* path_len, const float* cap,
+                           const long long* comm, float* max_lf, unsigned char* complete, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Stochastic path sampling of the REINFORCE training path, batched on the GPU.
  * Replaces PathSampler.sample / _sample_single_path / _top_p_sample (src/gcn/algorithms/path_sampler.py

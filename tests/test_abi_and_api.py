@@ -60,6 +60,7 @@ def test_plan_and_saved_layout_queries_without_gpu():
             assert lo + n <= total and lo not in seen       # inside the buffer, no two tensors at one offset
             seen.add(lo)
     assert lib.gcn_model_saved_layout(ctypes.byref(d), 3, off) != 0 and b"layer" in lib.gcn_last_error()
+    assert lib.gcn_load_factor_static(2, 1024, 1, 1024, None, None, None, None, None, None, None) == -1   # null pointers first
 
 
 class _Cfg(dict):
