@@ -18,6 +18,7 @@
 #include "kernels_bwd.hpp"
 #include "kernels_fwd.hpp"
 #include "kernels_strip.hpp"
+#include "kernels_strip2.hpp"
 #include "kernels_wide.hpp"
 #include "sampler.hpp"
 #include "dataset.hpp"
@@ -107,6 +108,8 @@ struct Dims {
     int IT, nit;     // i-chunk length / count of the edge backward pass
     int grid_f, grid_b;   // workgroups of the forward / backward edge kernel (upper bounds: no workgroup is left without work)
     int MT;
+    bool two_blocks;      // H of 2 or 4 column blocks: the edge kernels with two column blocks per wavefront (kernels_strip2.hpp)
+    bool fuse_wg;         // the edge backward kernel also forms the edge weight-gradient product (no det tensor in memory)
 };
 
 Dims make_dims(int B, int V, int C, int H) {
@@ -122,6 +125,17 @@ Dims make_dims(int B, int V, int C, int H) {
     auto balanced = [&](int it) { const int n = (V + it - 1) / it; return (V + n - 1) / n; };
     d.IT = balanced(target);
     d.grid_f = d.grid_b = 512;                              // two workgroups per CU
+    d.MT = (H + 15) / 16;
+    // Edge kernels with two column blocks per wavefront and the edge weight-gradient product inside the backward kernel
+    // (kernels_strip2.hpp): from about a million edge rows on, where the det tensor (written by the edge kernel, read
+    // back with the layer input by a product kernel) is HBM traffic worth removing: 200 nodes x 100 commodities runs 5 %
+    // faster with them and moves two edge tensors less per layer.  Below that everything sits in the caches and the
+    // kernels with one wavefront per column block are faster (same-box A/B: 3 % at nsfnet_10, 6 % at default2, 11 % at
+    // nsfnet_20): a wavefront's step is a chain of dependent phases, and twice the work per wavefront doubles it.
+    d.two_blocks = (d.MT == 2 || d.MT == 4) && d.Re >= 1000000;
+    if (const char* e = tune_env("GCN_TUNE_TWOBLOCKS")) d.two_blocks = (d.MT == 2 || d.MT == 4) && atoi(e) != 0;
+    d.fuse_wg = d.two_blocks;
+    if (const char* e = tune_env("GCN_TUNE_FUSE")) d.fuse_wg = d.two_blocks && atoi(e) != 0;
     if (H <= 64) {
         // Strip path: the edge kernels are issue bound, so a launch lasts as long as the busiest CU has 16-row steps to
         // issue: (workgroups on that CU) x (units per workgroup) x (steps per unit).  Grid (two or three workgroups per
@@ -145,12 +159,12 @@ Dims make_dims(int B, int V, int C, int H) {
                 }
             }
         d.grid_f = busiest((long long)d.Rn, grids[1], d.njt) < busiest((long long)d.Rn, grids[0], d.njt) ? grids[1] : grids[0];
+        if (d.two_blocks) d.grid_f = d.grid_b = 1024;           // workgroups of two wavefronts, four per CU (measured: 1024 and 2048 alike, 1536 5 % slower)
     } else if (d.IT > 3) {
         d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
     }
     if (const char* e = tune_env("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
-    d.MT = (H + 15) / 16;
     return d;
 }
 
@@ -244,15 +258,25 @@ int tn_slices(size_t rows, int H) {
 
 constexpr int kMaxPartBlocks = 2048;   // largest grid that writes rows of the BatchNorm-backward partial buffers
 
+// workgroups of the edge backward kernel (each writes one row of BatchNorm-backward partial sums and, on the strip
+// path, one slab of the edge weight gradient)
+int edge_bwd_blocks(const Dims& d) {
+    const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
+    int blocks = range_blocks(units, d.grid_b);
+    if (const char* e = tune_env("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
+    return blocks;
+}
+
 struct LayerBwdWs {
     float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
     float *tn_e, *tn_n;
-    int S_e, S_n;
+    int S_e, S_n;       // partial slabs of the edge / node weight-gradient products
 };
 LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
     LayerBwdWs w;
     const size_t nh = d.Rn * d.H;
-    w.S_e = tn_slices(d.Re, d.H);
+    // strip path: the edge product is part of the edge backward kernel, one slab per workgroup of that kernel
+    w.S_e = d.fuse_wg ? edge_bwd_blocks(d) : tn_slices(d.Re, d.H);
     w.S_n = tn_slices(d.Rn, d.H);
     w.det = b.f(d.Re * d.H);
     w.bpart_e = b.f((size_t)kMaxPartBlocks * 2 * d.H);
@@ -325,20 +349,30 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         const bool one = d.V <= 16;
         if constexpr (MT == 0) {
             GCN_LAUNCH_TIMED("k_edge_fwd_w", k_edge_fwd_w, W.nblk, 256, a);
-        } else if (a.src.mode == 0) {
-            if constexpr (MT != 0) {
-                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, true>), W.nblk, 64 * MT, a);
-                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, false>), W.nblk, 64 * MT, a);
-            }
-        } else if (a.src.mode == 1) {
-            if constexpr (MT != 0) {
-                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, true>), W.nblk, 64 * MT, a);
-                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, false>), W.nblk, 64 * MT, a);
-            }
         } else {
-            if constexpr (MT != 0) {
-                if (one) GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, true>), W.nblk, 64 * MT, a);
-                else GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, false>), W.nblk, 64 * MT, a);
+            bool launched = false;
+            if constexpr (MT == 2 || MT == 4) {
+                if (d.two_blocks) {          // two column blocks per wavefront
+                    switch (a.src.mode * 2 + (one ? 1 : 0)) {
+                        case 0: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 0, false>), W.nblk, 32 * MT, a); break;
+                        case 1: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 0, true>), W.nblk, 32 * MT, a); break;
+                        case 2: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 1, false>), W.nblk, 32 * MT, a); break;
+                        case 3: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 1, true>), W.nblk, 32 * MT, a); break;
+                        case 4: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 2, false>), W.nblk, 32 * MT, a); break;
+                        default: GCN_LAUNCH_TIMED("k_edge_fwd4", (k_edge_fwd4<MT, 2, true>), W.nblk, 32 * MT, a); break;
+                    }
+                    launched = true;
+                }
+            }
+            if (!launched) {
+                switch (a.src.mode * 2 + (one ? 1 : 0)) {
+                    case 0: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, false>), W.nblk, 64 * MT, a); break;
+                    case 1: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 0, true>), W.nblk, 64 * MT, a); break;
+                    case 2: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, false>), W.nblk, 64 * MT, a); break;
+                    case 3: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 1, true>), W.nblk, 64 * MT, a); break;
+                    case 4: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, false>), W.nblk, 64 * MT, a); break;
+                    default: GCN_LAUNCH_TIMED("k_edge_fwd3", (k_edge_fwd3<MT, 2, true>), W.nblk, 64 * MT, a); break;
+                }
             }
         }
     }
@@ -390,7 +424,7 @@ void bn_finish_job(ReduceJob& j, const float* partial, int nP, int H, double n, 
 template <int MT>
 int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
                     const float* const* P, const float* const* wT, const LayerSaved& S, float* dx, float* de,
-                    const LayerBwdWs& W, int& npart_e, const NextLayer& nx, hipStream_t st) {
+                    const float* e_in, float* tn_e, const LayerBwdWs& W, int& npart_e, const NextLayer& nx, hipStream_t st) {
     const int H = d.H;
     EdgeBwdArgs a = {};
     a.B = d.B; a.V = d.V; a.C = d.C; a.H = H; a.IT = d.IT; a.mean_agg = agg;
@@ -399,16 +433,25 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
     a.gamma_e = P[10]; a.beta_e = P[11]; a.gamma_x = P[8]; a.beta_x = P[9];
     a.bstats_e = W.bstats_e; a.bstats_x = W.bstats_x;
     a.det_out = W.det; a.rowpart = W.rowpart; a.colVe = W.colVe; a.colVn = W.colVn;
+    a.e_in = e_in; a.wg_out = tn_e;
     a.rng = rng; a.sid_e = 2 * sid; a.sid_x = 2 * sid + 1; a.p = p; a.training = training;
     if (nx.on) {
         a.next.tmp = nx.e_tmp; a.next.mean = nx.stats; a.next.rstd = nx.stats + H; a.next.gamma = nx.gamma_e;
         a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
     }
-    const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
-    int blocks = range_blocks(units, d.grid_b);
-    if (const char* e = tune_env("GCN_TUNE_GRID_B")) blocks = range_blocks(units, std::min(atoi(e), kMaxPartBlocks));
+    const int blocks = edge_bwd_blocks(d);
     if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
-    else GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
+    else {
+        bool launched = false;
+        if constexpr (MT == 2 || MT == 4) {
+            if (d.two_blocks) {
+                if (d.fuse_wg) GCN_LAUNCH_TIMED("k_edge_bwd4", (k_edge_bwd4<MT, true>), blocks, 32 * MT, a);
+                else GCN_LAUNCH_TIMED("k_edge_bwd4", (k_edge_bwd4<MT, false>), blocks, 32 * MT, a);
+                launched = true;
+            }
+        }
+        if (!launched) GCN_LAUNCH_TIMED("k_edge_bwd3", (k_edge_bwd3<MT>), blocks, 64 * MT, a);
+    }
     if (nx.on) npart_e = blocks;
     return 0;
 }
@@ -439,8 +482,8 @@ NodeBwdArgs node_bwd_args(const Dims& d, float p, int training, const unsigned l
 template <int MT>
 int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned long long* rng, int sid,
                    const float* const* P, const float* const* wT, const LayerSaved& S,
-                   float* dx, float* de, float* const* G, const LayerBwdWs& W, int& npart_e, int& npart_x,
-                   const NextLayer& nx, bool fin_first, hipStream_t st) {
+                   float* dx, float* de, const float* e_in, float* tn_e, float* const* G, const LayerBwdWs& W, int& npart_e,
+                   int& npart_x, const NextLayer& nx, bool fin_first, hipStream_t st) {
     const int H = d.H;
     if (fin_first) {
         ReduceJobs jobs = {};
@@ -451,7 +494,7 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
         k_reduce_slabs<<<dim3(red_grid(jobs), 2, 1), GCN_BLOCK, 0, st>>>(jobs);
         GCN_CHECK_LAUNCH("k_reduce_slabs(bn)");
     }
-    if (int rc = launch_edge_bwd<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, W, npart_e, nx, st)) return rc;
+    if (int rc = launch_edge_bwd<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, e_in, tn_e, W, npart_e, nx, st)) return rc;
     {
         const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
         const NodeBwdArgs a = node_bwd_args(d, p, training, rng, sid, P, wT, S, dx, W, W.dxtmp, W.dVn, W.dVe, nx);
@@ -470,7 +513,7 @@ void layer_tn_problems(TnProblems& pr, const Dims& d, const LayerBwdWs& W, const
     pr.X[1] = W.dxtmp; pr.Y[1] = x_in;   // node_feat.U
     pr.X[2] = W.dVn; pr.Y[2] = x_in;     // node_feat.V
     pr.X[3] = W.dVe; pr.Y[3] = x_in;     // edge_feat.V
-    pr.rows[0] = d.Re; pr.nslices[0] = W.S_e; pr.out[0] = tn_e; pr.out_stride[0] = slab;
+    pr.rows[0] = d.Re; pr.nslices[0] = d.fuse_wg ? 0 : W.S_e; pr.out[0] = tn_e; pr.out_stride[0] = slab;   // fused: done by the edge kernel
     for (int k = 1; k < 4; ++k) {
         pr.rows[k] = d.Rn; pr.nslices[k] = W.S_n; pr.out[k] = tn_n + (size_t)(k - 1) * slab; pr.out_stride[k] = 3 * slab;
     }
@@ -547,10 +590,10 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     GCN_CHECK_LAUNCH("k_bn_bwd_stats(nodes)");
     int npe = nblk_e, npx = nblk_x;
     NextLayer none = {};
-    if (int rc = layer_bwd_data<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, G, W, npe, npx, none, true, st)) return rc;
+    if (int rc = layer_bwd_data<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, e_in, W.tn_e, G, W, npe, npx, none, true, st)) return rc;
     TnProblems pr = {};
     layer_tn_problems(pr, d, W, x_in, e_in, W.tn_e, W.tn_n);
-    if (int rc = launch_tn<MT>(H, pr, 4, std::max(W.S_e, W.S_n), st)) return rc;
+    if (int rc = launch_tn<MT>(H, pr, 4, std::max(pr.nslices[0], W.S_n), st)) return rc;
     ReduceJobs jobs = {};
     jobs.n = 2;
     layer_wgrad_jobs(jobs.job[0], jobs.job[1], d, W, W.tn_e, W.tn_n, G);
@@ -793,7 +836,7 @@ int gcn_layer_plan(int B, int V, int C, int H, int out[8]) {
     const LayerFwdWs fw = carve_fwd_ws(d, f);
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
     out[0] = d.IT; out[1] = d.nit; out[2] = d.njt; out[3] = fw.nblk; out[4] = range_blocks(units, d.grid_b);
-    out[5] = d.MT > 4 ? 1 : 0; out[6] = 0; out[7] = 0;
+    out[5] = d.MT > 4 ? 1 : 0; out[6] = d.two_blocks ? 1 : 0; out[7] = 0;
     return 0;
 }
 
@@ -1069,8 +1112,8 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                 nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
             }
             int rc = 0;
-            DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de, LG, W.lw,
-                                                      npart_e, npart_x, nx, false, st));
+            DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de,
+                                                      e_act + (size_t)l * eh, nullptr, LG, W.lw, npart_e, npart_x, nx, false, st));
             if (rc) return rc;
             // one launch: this layer's weight-gradient products, the reduction of the layer above's products and the
             // BatchNorm-backward finish of the layer below (its partial sums were just written)
@@ -1138,7 +1181,8 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             }
             int rc = 0;
             DISPATCH_MT(d.MT, if constexpr (MT != 0) rc = launch_edge_bwd<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S,
-                                                                              W.dx, W.de, W.lw, npart_e, nx, st));
+                                                                              W.dx, W.de, e_act + (size_t)l * eh, tn_e_of(l), W.lw,
+                                                                              npart_e, nx, st));
             if (rc) return rc;
             NodeBwdArgs na = node_bwd_args(d, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.lw, ndbuf(l, 0), ndbuf(l, 1),
                                            ndbuf(l, 2), nx);
@@ -1147,8 +1191,10 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                 na.fin.dbeta = nx.G[9]; na.fin.dgamma = nx.G[8]; na.fin.bstats = W.lw.bstats_x; na.fin.inv_n = 1.0 / (double)d.Rn;
             }
             TnProblems pr = {};
-            pr.X[0] = W.lw.det; pr.Y[0] = e_act + (size_t)l * eh; pr.rows[0] = d.Re; pr.nslices[0] = W.lw.S_e;
-            pr.out[0] = tn_e_of(l); pr.out_stride[0] = slab;
+            if (!d.fuse_wg) {                 // fused: slot 0 stays empty, the edge product of layer l was part of its edge kernel
+                pr.X[0] = W.lw.det; pr.Y[0] = e_act + (size_t)l * eh; pr.rows[0] = d.Re; pr.nslices[0] = W.lw.S_e;
+                pr.out[0] = tn_e_of(l); pr.out_stride[0] = slab;
+            }
             if (l + 1 < p.L) node_problems(pr, 1, l + 1);
             ReduceJobs jobs = {};
             ReduceJob unused = {};

@@ -182,9 +182,12 @@ __device__ __forceinline__ void next_bn_accumulate(const NextBn& nb, float (*ncl
 //   de_in = dpre + det * W_U                                            (in place over de)
 // with qv[b,i,c] = dx_tmp / D formed on the fly from the node-side BatchNorm backward
 //   dx_tmp = gamma_x*rstd_x*(dbn_x - m1_x - xhat_x*m2_x).
-// Writes det (for the weight-gradient GEMM), row sums over j (rowpart[jt][b,i,c,:]), column sums over the
-// chunk's i (colVe[it][b,j,c,:] = sum_i det, colVn[it][b,j,c,:] = sum_i qv*g) and, if enabled, the
-// BatchNorm-backward statistics of layer l-1 computed from de_in.
+// Writes row sums over j (rowpart[jt][b,i,c,:]), column sums over the chunk's i (colVe[it][b,j,c,:] = sum_i det,
+// colVn[it][b,j,c,:] = sum_i qv*g) and, if enabled, the BatchNorm-backward statistics of layer l-1 computed from
+// de_in.  The weight gradient of edge_feat.U needs det^T e_in: the strip kernel (H <= 64) forms its workgroup's share
+// of that product from the det tile it holds in LDS and the matching tile of the layer's saved edge input, and
+// writes one H x H + H slab per workgroup at the end (wg_out; det itself never goes to memory); the wide kernel
+// writes det (det_out) for a separate product kernel.
 // ------------------------------------------------------------------------------------------------
 struct EdgeBwdArgs {
     int B, V, C, H, IT, mean_agg;
@@ -198,6 +201,8 @@ struct EdgeBwdArgs {
     float* det_out; float* rowpart; float* colVe; float* colVn;
     const unsigned long long* rng; int sid_e, sid_x; float p; int training;
     NextBn next;
+    const float* e_in;       // strip kernel: the layer's edge input (operand of the fused weight-gradient product)
+    float* wg_out;           // strip kernel: [gridDim.x][H*H + H] partial d edge_feat.U.weight / .bias
 };
 
 // ------------------------------------------------------------------------------------------------

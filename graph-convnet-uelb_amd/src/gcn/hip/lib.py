@@ -175,7 +175,8 @@ def layer_plan(B, V, C, H):
     (``row_chunk``), chunks per graph, j tiles, edge-kernel grids and whether the wide kernels run."""
     out = (c_int * 8)()
     check(load().gcn_layer_plan(B, V, C, H, out), "gcn_layer_plan")
-    return dict(row_chunk=out[0], n_chunks=out[1], j_tiles=out[2], grid_fwd=out[3], grid_bwd=out[4], wide=bool(out[5]))
+    return dict(row_chunk=out[0], n_chunks=out[1], j_tiles=out[2], grid_fwd=out[3], grid_bwd=out[4], wide=bool(out[5]),
+                two_blocks=bool(out[6]))
 
 
 def check(rc, what):

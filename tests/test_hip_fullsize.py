@@ -187,3 +187,14 @@ def test_layer_large_ragged_shape():
     stand-alone layer entry points (explicit BatchNorm-apply launches, their own statistics passes)."""
     from hip_layer_check import check_layer_against_oracle
     check_layer_against_oracle(1, 200, 25, 64, "mean", seed=11, e_scale=2.0, tag="fullsize layer V=200 C=25")
+
+
+def test_layer_two_block_kernels_at_32_channels():
+    """A million edge rows at H = 32: the edge kernels with two column blocks per wavefront in their one-wavefront form
+    (MT = 2), weight-gradient product fused into the backward kernel."""
+    from hip_layer_check import check_layer_against_oracle
+    from src.gcn.hip import lib as L
+    _dev()
+    assert L.layer_plan(1, 120, 70, 32)["two_blocks"] and L.layer_plan(1, 200, 25, 64)["two_blocks"]
+    assert not L.layer_plan(20, 14, 10, 64)["two_blocks"]
+    check_layer_against_oracle(1, 120, 70, 32, "sum", seed=12, e_scale=2.0, tag="fullsize layer V=120 C=70 H=32")
