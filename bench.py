@@ -14,8 +14,11 @@ Besides the headline value the line carries
   roofline     - the dominant kernel's algorithmic bytes per launch / its average duration, measured
                  with HIP events around each of its launches in an eager (non-graph) pass;
   cpu_baseline - the CPU oracle (oracle/gcn_oracle.py, a plain PyTorch restatement of the reference)
-                 timed on this box's host cores on the same batch, rank 0, N = 1 only;
-  beam_search  - graphs/sec of the batched GPU beam-search decode next to the C oracle (N = 1 only).
+                 timed on this box's host cores on the same batch (train and eval-with-gradient mode, all
+                 threads and one), rank 0, N = 1 only;
+  batch_sweep  - the same step at B = 20, 80, 320 graphs (headline workload only);
+  beam_search  - graphs/sec of the batched GPU beam-search decode next to the C oracle (N = 1 only), also at
+                 200 nodes x 100 commodities with the bytes of scores read per second.
 """
 import argparse
 import ctypes
@@ -48,22 +51,41 @@ def build_model(shape, device):
     return ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(device)
 
 
-def measured_traffic(config, graphs_per_gpu, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed counter passes (rocprofv3 --pmc cannot run
-    inside this process); None when they were taken on another workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def measured_traffic(config, graphs_per_gpu, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (rocprofv3 --pmc cannot run inside
+    this process): profiles/pmc_traffic.json holds one entry per (workload, graphs per GPU, kernel) together with the hash
+    of the library sources the passes were taken on (tools/pmc_traffic.sh writes it).  Returns (bytes or None, stale):
+    stale = an entry exists but was measured on other sources than the ones in the tree, and is therefore not reported."""
+    from src.gcn.hip import lib as L
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            t = json.load(f)
+            table = json.load(f)
     except (OSError, ValueError):
-        return None
-    if t.get("workload") == config and t.get("graphs_per_gpu") == graphs_per_gpu and t.get("kernel") == kernel:
-        return t.get("traffic_bytes_per_launch")
-    return None
+        return None, False
+    for e in table.get("entries", []):
+        if e.get("workload") == config and e.get("graphs_per_gpu") == graphs_per_gpu and str(e.get("kernel", "")).startswith(kernel_prefix):
+            if table.get("source_hash") != L.source_hash():
+                return None, True
+            return e.get("traffic_bytes_per_launch"), False
+    return None, False
 
 
-def cpu_baseline(shape, batch, max_seconds=25.0):
-    """fwd+bwd of the CPU oracle in train mode (dropout on, as the trainer runs) on the same batch."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(shape, batch):
+    """fwd+bwd of the CPU oracle on the same batch, in the two modes and at the two thread counts that matter:
+    train mode (dropout on: what the trainer runs; more than half of the reference's CPU step is the dropout mask
+    generator) and eval mode with gradients (dropout off: the parity mode), each with all host threads torch uses and
+    with one thread.  A bounded sample: about 25 s of CPU work in all."""
     from oracle import gcn_oracle
     from src.gcn.models.gcn_model import ResidualGatedGCNModel
     cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
@@ -76,27 +98,113 @@ def cpu_baseline(shape, batch, max_seconds=25.0):
     comm = torch.from_numpy(batch["commodities"])
     x_nodes = torch.from_numpy(batch["nodes"])
     y_edges = torch.from_numpy(batch["edges_target"])
-    cores = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
 
-    def one():
+    def one(training):
         for p in P.values():
             p.grad = None
-        _, loss = gcn_oracle.model_forward(P, ocfg, cap, comm, x_nodes, y_edges, batch["edge_cw"], training=True)
+        _, loss = gcn_oracle.model_forward(P, ocfg, cap, comm, x_nodes, y_edges, batch["edge_cw"], training=training)
         loss.backward()
 
-    one()                                     # warm-up
-    # a bounded sample: about 12 s of CPU work (at most 60 steps), at least two steps however long they take
-    times = []
-    t_end = time.time() + min(max_seconds, 12.0)
-    while len(times) < 60 and (time.time() < t_end or len(times) < 2):
-        t0 = time.time()
-        one()
-        times.append(time.time() - t0)
-    med = float(np.median(times))
-    return {"value": round(shape["B"] / med, 3), "unit": "graphs/s", "cores": int(cores), "kind": "port",
-            "ms_per_step": round(med * 1e3, 2),
-            "sample": f"{len(times)} fwd+bwd steps of the same B={shape['B']} batch, train mode (dropout on), "
-                      f"plain-PyTorch CPU oracle, torch threads={cores}"}
+    def timed(training, threads, budget_s, max_steps):
+        torch.set_num_threads(threads)
+        try:
+            one(training)                             # warm-up
+            times = []
+            t_end = time.time() + budget_s
+            while len(times) < max_steps and (time.time() < t_end or len(times) < 2):
+                t0 = time.time()
+                one(training)
+                times.append(time.time() - t0)
+        finally:
+            torch.set_num_threads(all_threads)
+        med = float(np.median(times))
+        return {"graphs_per_s": round(shape["B"] / med, 3), "ms_per_step": round(med * 1e3, 2), "threads": threads,
+                "steps_timed": len(times)}
+
+    modes = {
+        "train_all_threads": timed(True, all_threads, 8.0, 40),
+        "eval_grad_all_threads": timed(False, all_threads, 5.0, 40),
+        "train_1_thread": timed(True, 1, 4.0, 10),
+        "eval_grad_1_thread": timed(False, 1, 4.0, 10),
+    }
+    head = modes["train_all_threads"]
+    return {"value": head["graphs_per_s"], "unit": "graphs/s", "cores": int(all_threads), "kind": "port",
+            "ms_per_step": head["ms_per_step"], "cpu_model": cpu_model_name(), "host_cpus": os.cpu_count(),
+            "anomaly_detection": False,
+            "sample": f"median of {head['steps_timed']} fwd+bwd steps of the same B={shape['B']} batch, train mode (dropout on), "
+                      f"plain-PyTorch CPU oracle, torch threads={all_threads}; other modes and thread counts under 'modes' "
+                      f"(median of the steps each ran in a 4-8 s budget, at least 2)",
+            "modes": modes}
+
+
+def batch_sweep(name, shape, device, rank, batches=(20, 80, 320), steps=20):
+    """The headline step at larger batches of the same graphs (graph replay): 20 graphs are launch bound, this shows
+    where the same kernels go with more rows per launch.  Whole-step algorithmic GB/s = (20 L + 20) H R_e bytes / time."""
+    from src.common.synthetic import make_batch
+    from src.gcn.hip.train_step import HipTrainStep
+    out = []
+    V, C, H, Lr = shape["V"], shape["C"], shape["H"], shape["L"]
+    for B in batches:
+        batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
+                           seed=1234 + rank)
+        model = build_model(shape, device).train()
+        step = HipTrainStep(model, B, device, use_graph=True)
+        step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
+                        batch["edges_target"], batch["edge_cw"])
+        for _ in range(5):
+            step.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
+        out.append({"graphs_per_gpu": B, "ms_per_step": round(ms, 4), "graphs_per_s": round(B / ms * 1e3, 1),
+                    "whole_step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                    "whole_step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        del step, model
+        torch.cuda.empty_cache()
+    return {"workload": name, "mode": "train (dropout on), fwd+bwd, HIP graph replay", "points": out}
+
+
+def beam_bench_large(device, B=2, V=200, C=100, K=10):
+    """Beam-search decode at the largest BASELINE configuration (200 nodes x 100 commodities, K = 10, strict,
+    deterministic): graphs/s, and the bytes of the score tensor y the search reads (4 V^2 bytes per commodity) over the
+    decode time; the same decode by the C oracle on one host core next to it, paths compared bit for bit.  Scores favour
+    each commodity's labelled path, as a trained model's would, so that graphs decode completely."""
+    from oracle import beam_oracle_c
+    from src.common.synthetic import make_batch
+    from src.gcn.algorithms.beamsearch_uelb import BeamSearchFactory
+    b = make_batch(B, V, C, "random", 1000, 5000, 5, 500, seed=300)
+    rng = np.random.default_rng(V * 100 + C)
+    p = rng.random((B, V, V, C)).astype(np.float32) * 0.3 + 0.01
+    p[b["edges_target"] == 1] = 0.9
+    y = np.log(p).astype(np.float32)
+    cap = torch.from_numpy(b["edges_capacity"]).to(device)
+    comm = torch.from_numpy(b["commodities"]).to(device)
+    algo = BeamSearchFactory.create_algorithm("deterministic", y_pred_edges=torch.zeros((B, V, V, C), device=device), beam_size=K,
+                                              batch_size=B, edges_capacity=cap, commodities=comm, dtypeFloat=torch.float32,
+                                              dtypeLong=torch.long, mode_strict=True)
+    algo.y = torch.from_numpy(y).to(device)
+    algo.search()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.time()
+    for _ in range(reps):
+        paths, plen, feas, att = algo._run()
+    torch.cuda.synchronize()
+    gpu_s = (time.time() - t0) / reps
+    t0 = time.time()
+    rp, rl, rf, _, _ = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, "deterministic", True)
+    cpu_s = time.time() - t0
+    same = bool(np.array_equal(paths.cpu().numpy(), rp) and np.array_equal(plen.cpu().numpy(), rl))
+    y_bytes = 4.0 * B * V * V * C
+    return {"workload": f"V={V} C={C} K={K} strict deterministic, {B} graphs", "graphs_per_s": round(B / gpu_s, 2),
+            "ms_per_batch": round(gpu_s * 1e3, 3), "y_bytes": y_bytes, "y_GBps": round(y_bytes / gpu_s / 1e9, 2),
+            "feasible_graphs": int(np.sum(rf)), "cpu_oracle_graphs_per_s": round(B / cpu_s, 2), "cpu_cores": 1,
+            "paths_bit_exact_vs_oracle": same}
 
 
 def beam_bench(shape, batch, device, K=10):
@@ -191,6 +299,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-beam", action="store_true")
+    ap.add_argument("--skip-sweep", action="store_true", help="skip the batch sweep (B = 20, 80, 320) of the headline workload")
     ap.add_argument("--skip-opt", action="store_true", help="skip the extra leg that adds the optimizer step")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the broadcast / all-reduce even with one rank "
@@ -330,13 +439,14 @@ def main():
         lib.gcn_prof_end(ctypes.byref(tot_ms), ctypes.byref(n))
         avg_ms = tot_ms.value / max(n.value, 1)
         Re, Rn = B * V * V * C, B * V * C
+        traffic, traffic_stale = measured_traffic(args.config, B, dominant)
         # one launch = the edge backward of one layer: read d e_new, read the saved activation, write d e_in
         algo_bytes = 12.0 * H * (Re + Rn)
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         step_bytes = (20.0 * Lr + 20.0) * H * Re
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(args.config, B, dominant),
+                    "traffic": traffic, "traffic_stale": traffic_stale,
                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
                     "launches_timed": int(n.value),
                     "whole_step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)}
@@ -371,6 +481,16 @@ def main():
         }
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(shape, batch)
+        if world == 1 and not args.skip_sweep and args.config == "nsfnet_10_commodities" and not args.batch:
+            try:
+                out["batch_sweep"] = batch_sweep(args.config, shape, device, rank)
+            except Exception as ex:      # the headline metric must still be reported
+                out["batch_sweep"] = {"error": repr(ex)}
+        if world == 1 and not args.skip_beam:
+            try:
+                out["beam_search_200n_100c"] = beam_bench_large(device)
+            except Exception as ex:
+                out["beam_search_200n_100c"] = {"error": repr(ex)}
         if world == 1 and not args.skip_beam:
             try:
                 out["beam_search"] = beam_bench(shape, batch, device)

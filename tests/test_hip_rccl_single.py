@@ -26,7 +26,7 @@ def _bench(extra_args, extra_env):
     env = dict(os.environ)
     env.update(extra_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4",
-           "--skip-cpu", "--skip-beam", "--skip-opt"] + extra_args
+           "--skip-cpu", "--skip-beam", "--skip-opt", "--skip-sweep"] + extra_args
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -12,7 +12,7 @@ n=0
 for lib in "" graph-convnet-uelb_amd/lib/libgcn_alt*.so; do
   if [ -n "$lib" ]; then [ -f "$lib" ] || continue; export GCN_UELB_LIB=$PWD/$lib; fi
   echo "== ${lib:-main}"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$n -- python3 bench.py --config synthetic_100n_50c_h300_l30 --steps 2 --warmup 1 --skip-cpu --skip-beam --no-graph > gpurun_out/prof_${tag}_$n.log 2>&1 || { echo "rocprof run $n failed"; tail -5 gpurun_out/prof_${tag}_$n.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$n -- python3 bench.py --config synthetic_100n_50c_h300_l30 --steps 2 --warmup 1 --skip-cpu --skip-beam --skip-sweep --no-graph > gpurun_out/prof_${tag}_$n.log 2>&1 || { echo "rocprof run $n failed"; tail -5 gpurun_out/prof_${tag}_$n.log; exit 1; }
   python tools/prof_summary.py gpurun_out/prof_${tag}_$n 2>/dev/null | sed -n 1,4p
   n=$((n+1))
 done
