@@ -29,7 +29,7 @@ def main():
     config = manager.get_config()
     f, l = manager.get_dtypes()
     trainer = Trainer(config, f, l)
-    evaluator = Evaluator(config, f, l, strategy=None)
+    evaluator = Evaluator(config, f, l, strategy=trainer.strategy)      # as the reference (train_gcn.py:46)
     trainer.train(evaluator, None)
     if config.get('num_test_data', 0) >= config.batch_size:
         res = evaluator.evaluate(trainer.get_model(), None, mode='test')

@@ -37,6 +37,11 @@ class Trainer:
         self.models_dir = str(Path(root).expanduser())
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.net = ResidualGatedGCNModel(config, dtypeFloat, dtypeLong).to(self.device)
+        # pretrained weights, optionally a supervised two-class head converted to the REINFORCE score head
+        # (reference trainer.py:68-92; its load_saved_model branch is commented out there, :47-52, and has no effect)
+        if config.get('load_pretrained_model', False) and config.get('pretrained_model_path'):
+            self.load_checkpoint(str(Path(config.get('pretrained_model_path')).expanduser()),
+                                 convert_supervised_to_rl=bool(config.get('convert_supervised_to_rl', False)))
         D.broadcast_parameters(self.net.parameters())
         # the reference builds torch.optim.Adam(lr) here (trainer.py:95); same arithmetic and state layout, one launch per step
         self.optimizer = FusedAdam(self.net.parameters(), lr=config.learning_rate)
@@ -164,48 +169,124 @@ class Trainer:
         self.optimizer = update_learning_rate(self.optimizer, new_lr)
 
     def _get_config_hash(self):
-        keys = ['num_nodes', 'num_commodities', 'hidden_dim', 'num_layers', 'mlp_layers', 'aggregation', 'voc_edges_out',
-                'learning_rate', 'batch_size']
-        blob = json.dumps({k: self.config.get(k) for k in keys}, sort_keys=True)
-        return hashlib.md5(blob.encode()).hexdigest()[:8]
+        """md5 over the same configuration keys as the reference (trainer.py:271-309), so that checkpoint file names
+        agree for the same configuration."""
+        hash_keys = ['hidden_dim', 'num_layers', 'mlp_layers', 'node_dim', 'voc_nodes_out', 'voc_edges_in', 'voc_edges_out',
+                     'aggregation', 'dropout_rate', 'beam_size',
+                     'num_commodities', 'capacity_lower', 'capacity_higher', 'demand_lower', 'demand_higher', 'num_nodes',
+                     'sample_size',
+                     'learning_rate', 'batch_size', 'max_epochs', 'decay_rate',
+                     'training_strategy', 'reward_function_version',
+                     'solver_type', 'graph_model', 'expt_name']
+        cfg = dict(self.config)
+        picked = {k: cfg[k] for k in hash_keys
+                  if k in cfg and (isinstance(cfg[k], (int, float, str, bool)) or cfg[k] is None)}
+        return hashlib.md5(json.dumps(picked, sort_keys=True).encode()).hexdigest()[:8]
 
     def _get_model_filename(self, epoch=None):
         tag = "latest" if epoch is None else f"epoch_{epoch}"
         return f"model_{self._get_config_hash()}_{tag}.pt"
 
-    def save_model(self, epoch, loss):
+    def save_model(self, epoch, loss, save_latest=True):
+        """Checkpoint with the reference's keys and file names (trainer.py:375-412); rank 0 writes."""
         if D.rank() != 0:
             return None
         os.makedirs(self.models_dir, exist_ok=True)
+        cfg = self.config
         ckpt = {'epoch': epoch, 'model_state_dict': self.net.state_dict(), 'optimizer_state_dict': self.optimizer.state_dict(),
-                'loss': loss, 'config_hash': self._get_config_hash(), 'config': dict(self.config)}
-        path = os.path.join(self.models_dir, self._get_model_filename())
-        torch.save(ckpt, path)
-        if self.config.get('save_every_epoch', False):
+                'loss': loss, 'config_hash': self._get_config_hash(),
+                'config': {'hidden_dim': cfg.hidden_dim, 'num_layers': cfg.num_layers, 'mlp_layers': cfg.mlp_layers,
+                           'node_dim': cfg.get('node_dim'), 'voc_nodes_in': cfg.num_commodities * 3,
+                           'voc_nodes_out': cfg.get('voc_nodes_out'), 'voc_edges_in': cfg.voc_edges_in,
+                           'voc_edges_out': cfg.voc_edges_out, 'aggregation': cfg.aggregation,
+                           'dropout_rate': cfg.get('dropout_rate', 0.0)}}
+        path = None
+        if cfg.get('save_every_epoch', False):
             torch.save(ckpt, os.path.join(self.models_dir, self._get_model_filename(epoch)))
+        if save_latest:
+            path = os.path.join(self.models_dir, self._get_model_filename())
+            torch.save(ckpt, path)
         return path
+
+    def cleanup_old_models(self, keep_last_n=5):
+        """Keep the newest keep_last_n per-epoch checkpoints of this configuration (trainer.py:414-441)."""
+        if D.rank() != 0 or not os.path.exists(self.models_dir):
+            return
+        pattern = f"model_{self._get_config_hash()}_epoch_"
+        found = []
+        for name in os.listdir(self.models_dir):
+            if name.startswith(pattern) and name.endswith('.pt'):
+                try:
+                    found.append((int(name[len(pattern):-3]), name))
+                except ValueError:
+                    continue
+        for _, name in sorted(found)[:-keep_last_n] if len(found) > keep_last_n else []:
+            os.remove(os.path.join(self.models_dir, name))
+
+    def load_checkpoint(self, path, strict=True, convert_supervised_to_rl=False):
+        """Weights-only load of a checkpoint written by save_model or by the reference (whose state-dict keys carry the
+        ``module.`` prefix of nn.DataParallel, stripped here).  With convert_supervised_to_rl the two-class output layer
+        of a supervised model becomes the one-score layer of the REINFORCE model by the logit difference
+        (W1 - W0, b1 - b0), as the reference's model_converter.py:12-80 does.  Returns the checkpoint's epoch."""
+        ckpt = torch.load(path, map_location=self.device, weights_only=True)
+        sd = ckpt
+        if isinstance(ckpt, dict):
+            sd = ckpt.get('model_state_dict', ckpt.get('state_dict', ckpt))
+        out = {}
+        for k, v in sd.items():
+            k = k[len('module.'):] if k.startswith('module.') else k
+            if convert_supervised_to_rl and 'mlp_edges' in k and ('output_layer' in k or 'fc_out' in k) and v.shape[0] == 2:
+                v = v[1:2] - v[0:1]
+            out[k] = v
+        self.net.load_state_dict(out, strict=strict and not convert_supervised_to_rl)
+        D.broadcast_parameters(self.net.parameters())
+        return ckpt.get('epoch') if isinstance(ckpt, dict) else None
 
     # ------------------------------------------------------------------ whole run
     def train(self, evaluator=None, metrics_logger=None):
+        """The reference's schedule (trainer.py:482-584), epochs counted from 0: validation when
+        ``epoch % val_every == 0`` or on the last epoch, the learning rate divided by ``decay_rate`` when
+        ``epoch % val_every == 0 and epoch != 0`` (whether or not an evaluator is given), test when
+        ``epoch % test_every == 0`` or on the last epoch, a checkpoint after every epoch unless ``save_model`` is false.
+        Returns the trained network, as the reference does; the per-epoch numbers are kept in ``self.history``."""
         cfg = self.config
-        lr = cfg.learning_rate
-        history = []
-        for epoch in range(cfg.max_epochs):
+        max_epochs = cfg.max_epochs
+        val_every, test_every = cfg.get('val_every', 1), cfg.get('test_every', max(max_epochs, 1))
+        lr, decay_rate = cfg.learning_rate, cfg.get('decay_rate', 1.0)
+        self.history = []
+        for epoch in range(max_epochs):
             if hasattr(self.strategy, 'set_epoch'):
                 self.strategy.set_epoch(epoch)
             t, loss, err, rl = self.train_one_epoch()
-            line = f"epoch {epoch + 1}/{cfg.max_epochs}  time {t:.2f}s  lr {lr:.2e}  loss {loss:.4f}  err_edges {err:.2f}"
-            if evaluator is not None and (epoch + 1) % cfg.get('val_every', 1) == 0:
-                res = evaluator.evaluate(self.net, None, mode='val')
-                line += f"  val_loss {res[1]:.4f}  val_load_factor {res[2]:.4f}  infeasible% {res[5]:.1f}"
-                lr /= cfg.get('decay_rate', 1.0)
-                self.update_learning_rate(lr)
+            if metrics_logger is not None:
+                metrics_logger.log_train_metrics(loss, err, t)
+                if rl:
+                    metrics_logger.log_rl_metrics(epoch, rl)
+            line = f"epoch {epoch + 1}/{max_epochs}  time {t:.2f}s  lr {lr:.2e}  loss {loss:.4f}  err_edges {err:.2f}"
             if rl:
                 line += (f"  reward {rl['reward']:.4f}  entropy {rl.get('entropy', 0):.4f}  complete% {rl.get('complete_paths_rate', 0):.1f}"
                          f"  T {rl.get('temperature', 0):.2f}")
+            last = epoch == max_epochs - 1
+            if evaluator is not None and (epoch % val_every == 0 or last):
+                self.net.eval()
+                res = evaluator.evaluate(self.net, None, mode='val')
+                if metrics_logger is not None:
+                    metrics_logger.log_val_metrics(res[4], res[0], epoch=epoch, comp_rate=res[6], comp_sample_rate=res[7])
+                line += f"  val_loss {res[1]:.4f}  val_load_factor {res[2]:.4f}  approx% {res[4]:.1f}  infeasible% {res[5]:.1f}"
+            if epoch % val_every == 0 and epoch != 0:
+                lr /= decay_rate
+                self.update_learning_rate(lr)
+            if evaluator is not None and cfg.get(f'num_test_data', 0) and (epoch % test_every == 0 or last):
+                self.net.eval()
+                res = evaluator.evaluate(self.net, None, mode='test')
+                if metrics_logger is not None:
+                    metrics_logger.log_test_metrics(res[4], res[0], epoch=epoch, comp_rate=res[6], comp_sample_rate=res[7])
+                line += f"  test_loss {res[1]:.4f}  test_load_factor {res[2]:.4f}"
             if D.rank() == 0:
                 print(line, flush=True)
-            history.append((epoch + 1, t, loss, err))
-            if cfg.get('save_model', False):
-                self.save_model(epoch + 1, loss)
-        return history
+            self.history.append((epoch + 1, t, loss, err))
+            if cfg.get('save_model', True):
+                self.save_model(epoch, loss)
+                if cfg.get('cleanup_old_models', True):
+                    self.cleanup_old_models()
+        return self.net
