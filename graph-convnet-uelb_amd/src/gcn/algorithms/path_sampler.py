@@ -8,10 +8,11 @@ edges_capacity, commodities, num_samples, temperature, top_p, entropy_epsilon, d
 model exactly as in the reference (``src/gcn/training/reinforcement_strategy.py:427-428``).
 
 All (graph, commodity) pairs are sampled by one kernel launch.  The draws come from a counter-based generator
-keyed by (seed, call counter, graph, commodity, step): the seed is taken from ``torch.initial_seed()`` and the
-counter advances by one per ``sample()`` call, so a run is reproducible under ``torch.manual_seed`` but does
-not consume torch's generator the way the reference's ``torch.multinomial`` calls do; the distribution of the
-paths is the same.
+keyed by (seed, call counter, graph, commodity, step): the seed is ``torch.initial_seed()`` with the process
+rank mixed in and the counter advances by one per ``sample()`` call, so a run is reproducible from
+``torch.manual_seed(s)`` followed by ``src.gcn.hip.lib.reseed()`` (which restarts the counter), but it does not
+consume torch's generator the way the reference's ``torch.multinomial`` calls do; the distribution of the paths
+is the same.
 """
 from __future__ import annotations
 
@@ -22,12 +23,23 @@ from ..hip import lib as L
 _calls = {}
 
 
+def reset_call_counters():
+    """Restart the draw streams (called by ``lib.reseed``): the next ``sample()`` uses call counter 0 again."""
+    _calls.clear()
+
+
+L.register_reseed_hook(reset_call_counters)
+
+
 def _rng_words(dev):
-    """{seed, call counter} on the device; the counter advances with every call."""
-    key = (dev.index, torch.initial_seed())
+    """{seed, call counter} on the device.  The seed is ``lib.base_seed()`` (torch's initial seed with the rank of
+    this process mixed in, so that ranks seeded alike draw differently for their different graphs); the counter
+    advances with every call and starts again at 0 after ``lib.reseed()`` - calling ``torch.manual_seed`` alone does
+    not restart it."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), L.base_seed())
     n = _calls.get(key, 0)
     _calls[key] = n + 1
-    return torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, n], dtype=torch.int64, device=dev)
+    return torch.tensor([L.base_seed(), n], dtype=torch.int64, device=dev)
 
 
 def _commodity_tensor(commodities, B, dev):

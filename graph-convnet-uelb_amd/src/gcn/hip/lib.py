@@ -236,21 +236,73 @@ def workspace(device, nbytes):
     return buf
 
 
+def base_seed():
+    """The seed of every counter-based generator of the library (dropout masks, path sampling): torch's initial seed
+    with the rank of this process mixed in, so that data-parallel ranks seeded alike still draw different masks and
+    paths for their different graphs.  63 bits (stored in int64 tensors)."""
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    seed = torch.initial_seed() if _seed_override is None else _seed_override
+    return (seed + rank * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+
+
+_seed_override = None      # set by reseed(seed): replaces torch's initial seed until reseed() is called without one
+
+
+_reseed_hooks = []
+_step_states = []          # weak references to {seed, step} tensors owned by HipTrainStep objects
+
+
+def register_reseed_hook(fn):
+    _reseed_hooks.append(fn)
+
+
+def register_step_state(t):
+    import weakref
+    _step_states.append(weakref.ref(t))
+
+
+def _dev_index(device):
+    if device is None:
+        return None
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def rng_state(device):
     """Device-resident {seed, step} words read by the dropout code of the kernels."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = _dev_index(device)
     st = _rng.get(key)
     if st is None:
-        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        st = torch.tensor([base_seed(), 0], dtype=torch.int64, device=device)
         _rng[key] = st
     return st
 
 
-def reseed(seed, device=None):
-    """Restart the dropout stream (all devices if device is None)."""
+def reseed(seed=None, device=None):
+    """Restart every generator of the library from ``seed`` (default: what the last ``torch.manual_seed`` set;
+    either way with the rank mixed in, see ``base_seed``): the dropout {seed, step} words of the autograd path and of every live HipTrainStep
+    (on ``device``, or on all devices), and the call counters of the path sampler.  ``torch.manual_seed(s)`` followed
+    by ``reseed()`` reproduces a run; ``torch.manual_seed`` alone does not rewind the step and call counters."""
+    global _seed_override
+    _seed_override = None if seed is None else int(seed)
+    seed = base_seed()
+    want = _dev_index(device)
+    fresh = torch.tensor([seed, 0], dtype=torch.int64)
     for key, st in list(_rng.items()):
-        if device is None or key == device.index:
-            st.copy_(torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+        if want is None or key == want:
+            st.copy_(fresh)
+    alive = []
+    for ref in _step_states:
+        t = ref()
+        if t is not None:
+            alive.append(ref)
+            if want is None or _dev_index(t.device) == want:
+                t.copy_(fresh)
+    _step_states[:] = alive
+    for fn in _reseed_hooks:
+        fn()
 
 
 def next_rng_snapshot(device):

@@ -59,7 +59,8 @@ class HipTrainStep:
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.counts = torch.zeros(2 * B * C, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(B * C, dtype=torch.uint8, device=dev)
-        self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+        self.rng = torch.tensor([L.base_seed(), 0], dtype=torch.int64, device=dev)
+        L.register_step_state(self.rng)          # lib.reseed() restarts this step's dropout stream too
         self._param_ptrs = L.ptr_array(self.params)
         self._grad_ptrs = L.ptr_array(self.grad_views)
 

@@ -113,7 +113,7 @@ class Trainer:
                     sub = type(batch)({k: (v[lo:hi] if hasattr(v, "__len__") and len(v) == batch_size else v) for k, v in batch.items()})
                     data = self.strategy.prepare_batch_data(sub, self.device)
                 loss, metrics = self.strategy.compute_loss(self.net, data, self.device)
-                self._sync_grads = True
+                self._sync_grads = not getattr(self.strategy, 'syncs_gradients', False)
                 self.strategy.backward_step(loss, self.optimizer, acc, batch_num)
                 self._sync_grads = False
                 loss_val, err_val = float(loss.item()), metrics.get('edge_error', 0.0)

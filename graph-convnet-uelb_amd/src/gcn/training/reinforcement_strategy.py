@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ..hip import dist as D
 from ...common.graph.graph_utils import load_factor_from_tensors
 from ..algorithms.beamsearch_uelb import BeamSearchFactory
 from ..algorithms.path_sampler import PathSampler
@@ -161,21 +162,35 @@ class ReinforcementLearningStrategy(BaseTrainingStrategy):
         }
         rewards = torch.tensor([self._reward(lf[i], int((~done[i]).sum())) for i in range(B)], dtype=torch.float32, device=dev)
 
-        # baseline and advantages (reference :383-416)
+        # baseline and advantages (reference :383-416).  Under several ranks the reward mean, and the mean and standard
+        # deviation used to normalise the advantages, are those of the GLOBAL batch (sums all-reduced over the ranks), so
+        # that every rank keeps the same moving baseline and N ranks do what one process does on the whole batch.
+        n_glob, r_mean = float(B), rewards.mean().item()
+        if D.world() > 1:
+            acc = torch.stack([rewards.double().sum(), torch.tensor(float(B), dtype=torch.float64, device=dev)])
+            D.allreduce_sum_(acc)
+            n_glob, r_mean = acc[1].item(), (acc[0] / acc[1]).item()
         if self.reward_baseline is None:
-            self.reward_baseline = rewards.mean().item()
+            self.reward_baseline = r_mean
         baseline_before = self.reward_baseline
         if self.use_baseline:
             advantages = rewards - self.reward_baseline
             self.reward_baseline = (self.baseline_momentum * self.reward_baseline
-                                    + (1 - self.baseline_momentum) * rewards.mean().item())
+                                    + (1 - self.baseline_momentum) * r_mean)
         else:
             advantages = rewards
         adv_pre = advantages.detach().clone()
-        if self.normalize_advantages and B > 1:
-            std = advantages.std()
+        if self.normalize_advantages and n_glob > 1:
+            if D.world() > 1:
+                acc = torch.stack([advantages.double().sum(), (advantages.double() ** 2).sum()])
+                D.allreduce_sum_(acc)
+                a_mean = acc[0] / n_glob
+                std = torch.sqrt(torch.clamp(acc[1] - n_glob * a_mean * a_mean, min=0.0) / (n_glob - 1)).float()
+                a_mean = a_mean.float()
+            else:
+                std, a_mean = advantages.std(), advantages.mean()
             if not std < 1e-8:
-                advantages = (advantages - advantages.mean()) / (std + 1e-8)
+                advantages = (advantages - a_mean) / (std + 1e-8)
         adv_post = advantages.detach().clone()
 
         # policy loss (reference :418-453)
@@ -222,9 +237,15 @@ class ReinforcementLearningStrategy(BaseTrainingStrategy):
         return total_loss, metrics
 
     # ------------------------------------------------------------------ backward (reference :628-777)
+    # This strategy averages its gradients over the ranks itself (before clipping): the trainer must not do it again.
+    syncs_gradients = True
+
     def backward_step(self, loss, optimizer, accumulation_steps=1, batch_num=0):
         (loss / accumulation_steps).backward()
         params = [p for group in optimizer.param_groups for p in group['params'] if p.grad is not None]
+        if (batch_num + 1) % accumulation_steps == 0:
+            # mean over the ranks first, then norm and clip: clip(mean(g_r)), what one process on the whole batch computes
+            D.allreduce_mean_grads(params)
         with torch.no_grad():
             total = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in params])).item() if params else 0.0
         self.grad_norm_history.append(total)

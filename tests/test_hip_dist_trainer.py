@@ -40,9 +40,15 @@ def _worker(rank, world, port, root, strategy, packed, out):
                             training_strategy=strategy, beam_size=2, seed=5))
         torch.manual_seed(100 + rank)               # different initial weights: the broadcast must make them equal
         tr = Trainer(cfg, torch.float32, torch.long)
+        from src.gcn.hip import lib as L
+        torch.manual_seed(7)                        # both ranks seeded alike from here on: the rank still separates
+        L.reseed()                                  # their dropout and sampling streams
         t, loss, err, rl = tr.train_one_epoch()
         flat = torch.cat([p.detach().reshape(-1) for p in tr.get_model().parameters()]).cpu()
-        cw = None if strategy != "supervised" else tr.strategy.edge_cw.cpu().numpy().tolist()
+        if strategy == "supervised":
+            cw = tr.strategy.edge_cw.cpu().numpy().tolist()
+        else:
+            cw = dict(baseline=tr.strategy.reward_baseline, seed=L.base_seed(), grad_norm=rl.get("grad_norm") if isinstance(rl, dict) else None)
         out.put((rank, "ok", float(loss), flat.numpy(), cw))
     except Exception as ex:  # pragma: no cover
         import traceback
@@ -78,6 +84,11 @@ def test_two_ranks_end_with_identical_parameters(strategy, packed, tmp_path):
     np.testing.assert_array_equal(res[0][3], res[1][3])          # same parameters on both ranks, bit for bit
     if strategy == "supervised":
         assert res[0][4] == res[1][4]                            # class weights from the global label counts
+    else:
+        # the moving reward baseline follows the GLOBAL batch mean, so the ranks agree on it exactly; their sampler
+        # and dropout streams differ (rank mixed into the seed) although both were seeded alike by the config
+        assert res[0][4]["baseline"] == res[1][4]["baseline"] and np.isfinite(res[0][4]["baseline"])
+        assert res[0][4]["seed"] != res[1][4]["seed"]
 
 
 def _grad_worker(rank, world, port, out):
