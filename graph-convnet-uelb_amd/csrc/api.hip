@@ -641,7 +641,6 @@ int check_model(const gcn_model_desc* m) {
     if (int rc = check_dims(m->B, m->V, m->C, m->H)) return rc;
     if (m->L < 1) return fail(-1, "num_layers %d < 1", m->L);
     if (m->L > 64) return fail(-1, "num_layers %d > 64 is not supported by this build", m->L);
-    if (m->H > 64 && m->mlp_layers > 2) return fail(-1, "hidden_dim %d > 64 supports mlp_layers <= 2 (got %d)", m->H, m->mlp_layers);
     if (m->mlp_layers < 1 || m->mlp_layers > GCN_MAX_MLP_LAYERS) return fail(-1, "mlp_layers %d outside 1..%d", m->mlp_layers, GCN_MAX_MLP_LAYERS);
     if (m->voc_out != 1 && m->voc_out != 2) return fail(-1, "voc_edges_out %d must be 1 or 2", m->voc_out);
     if (m->H % 2 != 0) return fail(-1, "hidden_dim must be even");
@@ -656,6 +655,7 @@ struct ModelFwdWs {
     float* loss_partial;
     int* count_rep;                 // [kCountReps][2][B*C]
     int head_blk;
+    float* hid[2];                  // above 64 channels, MLPs with several hidden layers: outputs of the hidden layers before the last
 };
 ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     ModelFwdWs w;
@@ -663,6 +663,9 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     w.head_blk = wave_blocks((p.d.Re + 15) / 16);
     w.loss_partial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * 2);
     w.count_rep = (int*)b.raw((size_t)kCountReps * 2 * p.d.B * p.d.C * sizeof(int));
+    const bool deep_wide = p.d.MT > 4 && p.NHID > 1;
+    w.hid[0] = deep_wide ? b.f(p.d.Re * p.d.H) : nullptr;
+    w.hid[1] = deep_wide && p.NHID > 2 ? b.f(p.d.Re * p.d.H) : nullptr;
     return w;
 }
 struct ModelBwdWs {
@@ -979,10 +982,32 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     const HeadParams hp = head_params(p, P);
     const PrevLayer last = prev_of(p, saved, P, p.L - 1);
     const EdgeSrc src = make_edge_src(last, nullptr, nullptr, H, m->p_layer, m->training);
-    GCN_PROF_PRE("k_head_fwd");
-    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, src, cap, y_edges, edge_cw, y_pred,
-                                                                      W.loss_partial, counts, nrep, rng, W.head_blk, st))));
-    GCN_CHECK_LAUNCH("k_head_fwd");
+    if (d.MT > 4 && p.NHID > 1) {
+        // hidden layers 0 .. NHID-2 one launch each, then the fused head on the last hidden layer and the output layer
+        EdgeSrc cur = src;
+        for (int k = 0; k + 1 < p.NHID; ++k) {
+            float* out = W.hid[k & 1];
+            GCN_PROF_PRE("k_mlp_hidden_fwd_w");
+            k_mlp_hidden_fwd_w<<<W.head_blk, 256, 0, st>>>(d.Re, d.C, H, hp.hidW[k], hp.hidB[k], cur, nullptr, out, rng, 1000 + k,
+                                                           m->p_mlp, m->training);
+            GCN_CHECK_LAUNCH("k_mlp_hidden_fwd_w");
+            cur = EdgeSrc{};
+            cur.mode = 0; cur.e_in = out;
+        }
+        HeadParams hl = {};
+        hl.hidW[0] = hp.hidW[p.NHID - 1]; hl.hidB[0] = hp.hidB[p.NHID - 1]; hl.outW = hp.outW; hl.outB = hp.outB;
+        GCN_PROF_PRE("k_head_fwd");
+        k_head_fwd_w<1><<<W.head_blk, 256, 0, st>>>(d.Re, d.V, d.C, H, p.voc, hl, cur, cap, m->mask_invalid_edges,
+                                                    m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                    m->has_labels ? W.loss_partial : nullptr, counts, rng, 1000 + p.NHID - 1,
+                                                    m->p_mlp, m->training);
+        GCN_CHECK_LAUNCH("k_head_fwd");
+    } else {
+        GCN_PROF_PRE("k_head_fwd");
+        DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_fwd<MT, NHID>(p, m, hp, src, cap, y_edges, edge_cw, y_pred,
+                                                                          W.loss_partial, counts, nrep, rng, W.head_blk, st))));
+        GCN_CHECK_LAUNCH("k_head_fwd");
+    }
     if (m->has_labels) {
         GCN_PROF_PRE("k_loss_finalize");
         k_loss_finalize<<<1, GCN_BLOCK, 0, st>>>(W.loss_partial, p.whead ? W.head_blk : W.head_blk * GCN_WAVES_PER_BLOCK, counts, d.B * d.C, nrep,
@@ -1020,7 +1045,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         const int idx[4] = {0, 2, 4, 6};
         for (int l = 0; l < p.L; ++l)
             for (int k = 0; k < 4; ++k) tr.emplace_back(P[3 + GCN_LAYER_NPARAMS * l + idx[k]], W.wT + (size_t)(4 * l + k) * hh2);
-        if (p.whead && p.NHID == 1) tr.emplace_back(hp.hidW[0], W.wT + (size_t)4 * p.L * hh2);   // the tile-per-workgroup head reads W_0^T
+        for (int k = 0; k < p.NHID; ++k) tr.emplace_back(hp.hidW[k], W.wT + (size_t)(4 * p.L + k) * hh2);   // the head reads W_k^T
         for (size_t i0 = 0; i0 < tr.size(); i0 += 64) {
             TransposeList tl = {};
             const int n = (int)std::min<size_t>(64, tr.size() - i0);
@@ -1042,11 +1067,45 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     hz.p[0] = W.dx; hz.n[0] = nh;
     hz.p[1] = W.lw.bpart_x; hz.n[1] = 2 * (size_t)H;
     hz.p[2] = reinterpret_cast<float*>(W.fin_counters); hz.n[2] = 4;
-    GCN_PROF_PRE("k_head_bwd");
-    DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
-                                                                      dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
-                                                                      W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2, st))));
-    GCN_CHECK_LAUNCH("k_head_bwd");
+    if (d.MT > 4 && p.NHID > 1) {
+        // (1) the hidden layers before the last once more (h_stash[k] = output of hidden layer k; the first also
+        //     stores the head's input), (2) the fused head backward on the last hidden layer and the output layer,
+        //     (3) the earlier hidden layers backwards, in place in de; the first one adds the BatchNorm-backward sums
+        //     of the last conv layer
+        EdgeSrc cur = src;
+        for (int k = 0; k + 1 < p.NHID; ++k) {
+            float* out = W.h_stash + (size_t)k * eh;
+            GCN_PROF_PRE("k_mlp_hidden_fwd_w");
+            k_mlp_hidden_fwd_w<<<W.head_blk, 256, 0, st>>>(d.Re, d.C, H, hp.hidW[k], hp.hidB[k], cur, k == 0 ? W.eL : nullptr, out, rng,
+                                                           1000 + k, m->p_mlp, m->training);
+            GCN_CHECK_LAUNCH("k_mlp_hidden_fwd_w");
+            cur = EdgeSrc{};
+            cur.mode = 0; cur.e_in = out;
+        }
+        HeadParams hl = {};
+        hl.hidW[0] = hp.hidW[p.NHID - 1]; hl.hidB[0] = hp.hidB[p.NHID - 1]; hl.outW = hp.outW; hl.outB = hp.outB;
+        GCN_PROF_PRE("k_head_bwd");
+        k_head_bwd_w<1><<<W.head_blk, 256, 0, st>>>(d.Re, d.V, d.C, H, p.voc, hl, W.wT + (size_t)(4 * p.L + p.NHID - 1) * hh2, cur,
+                                                    NextBn{}, nullptr, cap, m->mask_invalid_edges, m->has_labels ? y_edges : nullptr,
+                                                    edge_cw, loss_out, dloss, dy_pred, W.de, dpre_all + (size_t)(p.NHID - 1) * eh,
+                                                    W.wpartial, rng, 1000 + p.NHID - 1, m->p_mlp, m->training, hz);
+        GCN_CHECK_LAUNCH("k_head_bwd");
+        for (int k = p.NHID - 2; k >= 0; --k) {
+            NextBn nb = {};
+            if (k == 0) { nb = hnext; nb.drop_sid = src.drop_sid; }
+            GCN_PROF_PRE("k_mlp_hidden_bwd_w");
+            k_mlp_hidden_bwd_w<<<W.head_blk, 256, 0, st>>>(d.Re, H, W.wT + (size_t)(4 * p.L + k) * hh2, W.h_stash + (size_t)k * eh, W.de,
+                                                           dpre_all + (size_t)k * eh, nb, src.drop_p, src.drop_on, rng, 1000 + k,
+                                                           m->p_mlp, m->training);
+            GCN_CHECK_LAUNCH("k_mlp_hidden_bwd_w");
+        }
+    } else {
+        GCN_PROF_PRE("k_head_bwd");
+        DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
+                                                                          dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
+                                                                          W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2, st))));
+        GCN_CHECK_LAUNCH("k_head_bwd");
+    }
     int npart_e = W.head_blk, npart_x = 1;
     // hidden-layer weight-gradient products of the head and the reduce jobs that are ready now: output-layer
     // gradients and the BatchNorm backward of the top layer.  The slabs of the head's products are reduced by the

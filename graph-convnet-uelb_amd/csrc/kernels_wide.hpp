@@ -1307,6 +1307,166 @@ __global__ __launch_bounds__(256, 2) void k_head_bwd_w(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Edge MLPs with more than one hidden layer (MLP, gcn_layers.py:135-165): the last hidden layer and the output layer
+// run in the fused head kernels above, every hidden layer before them is a launch of its own.
+//   forward : hout = dropout(relu(src W^T + b))          (src: EdgeSrc, i.e. the fused apply of the last conv layer
+//                                                          for the first hidden layer, a stored activation after it)
+//   backward: dpre = dh * [hout > 0] * dropout multiplier  -> dpre_stash (operand of the weight gradient)
+//             dh  <- dpre W                                 (in place: a step reads its rows whole before it writes)
+//             and, for the first hidden layer, the BatchNorm-backward sums of the last conv layer as in k_head_bwd_w.
+// Steps of up to WNS 16-row tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_mlp_hidden_fwd_w(
+    size_t rows, int C, int H, const float* __restrict__ W, const float* __restrict__ bias, EdgeSrc src,
+    float* __restrict__ e_stash, float* __restrict__ hout, const unsigned long long* __restrict__ rng, int stream_id,
+    float p, int training) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    const WideIdx ix = wide_idx();
+    const int NB = (H + 15) / 16, HP = 16 * NB;
+    clds_fill(cl[CL_PMEAN], src.mode == 1 ? src.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], src.mode == 1 ? src.prstd : nullptr, H, HP);
+    clds_fill(cl[CL_PGAMMA], src.mode == 1 ? src.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], src.mode == 1 ? src.pbeta : nullptr, H, HP);
+    clds_fill(cl[CL_WE], src.mode == 2 ? src.we : nullptr, H, HP);
+    wide_zero_pad(tile, NB, ix.t);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id, p, training);
+    const rsrc_t rW = make_rsrc(W, (uint32_t)H * H * 4);
+    const size_t ntiles = (rows + 15) / 16, nsteps = (ntiles + WNS - 1) / WNS;
+    __syncthreads();
+    for (size_t stp = blockIdx.x; stp < nsteps; stp += gridDim.x) {
+        const int ns = (int)min((size_t)WNS, ntiles - stp * WNS);
+#pragma unroll
+        for (int s = 0; s < WNS; ++s)
+            if (s < ns) head_src_tile(tile + 16 * s, src, cl, sdc, (stp * WNS + s) * 16, rows, H, HP, C, e_stash, ix);
+        __syncthreads();
+#pragma unroll 1
+        for (int kk = 0; kk < WKB; ++kk) {
+            const int nb = ix.w + 4 * kk;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                f32x4 h[WNS];
+                wide_gemm_n<0>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, h);
+                if (bcol < H) {
+                    const f32x4 hb = ld4(bias + bcol);
+#pragma unroll
+                    for (int s = 0; s < WNS; ++s) {
+                        const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                        if (s < ns && row < rows) {
+                            f32x4 hv = h[s] + hb;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hv[r] = hv[r] > 0.f ? hv[r] : 0.f;
+                            if (hdc.on) hv *= drop_mul4(hdc, drop_rowhash(hdc, (uint32_t)row), bcol >> 2);
+                            st4(hout + row * H + bcol, hv);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_mlp_hidden_bwd_w(
+    size_t rows, int H, const float* __restrict__ Wt, const float* __restrict__ hout, float* __restrict__ dh,
+    float* __restrict__ dpre_stash, NextBn next, float next_drop_p, int next_drop_on,
+    const unsigned long long* __restrict__ rng, int stream_id, float p, int training) {
+    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
+    __shared__ __attribute__((aligned(16))) float cl[4][GCN_WIDE_MAX_H];
+    __shared__ __attribute__((aligned(16))) float nacc[2][GCN_WIDE_MAX_H];     // BatchNorm-backward sums of the last conv layer
+    const WideIdx ix = wide_idx();
+    const int NB = (H + 15) / 16, HP = 16 * NB;
+    const bool do_next = next.tmp != nullptr;
+    clds_fill(cl[0], do_next ? next.mean : nullptr, H, HP); clds_fill(cl[1], do_next ? next.rstd : nullptr, H, HP);
+    clds_fill(cl[2], do_next ? next.gamma : nullptr, H, HP); clds_fill(cl[3], do_next ? next.beta : nullptr, H, HP);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&nacc[0][0])[k] = 0.f;
+    wide_zero_pad(tile, NB, ix.t);
+    const DropCfg hdc = drop_cfg(rng, stream_id, p, training);
+    const DropCfg ndc = drop_cfg(rng, next.drop_sid, next_drop_p, next_drop_on && do_next);
+    const rsrc_t rWt = make_rsrc(Wt, (uint32_t)H * H * 4);
+    const size_t ntiles = (rows + 15) / 16, nsteps = (ntiles + WNS - 1) / WNS;
+    __syncthreads();
+    for (size_t stp = blockIdx.x; stp < nsteps; stp += gridDim.x) {
+        const int ns = (int)min((size_t)WNS, ntiles - stp * WNS);
+        // ---- phase A: dpre of the step's rows -> dpre_stash and LDS
+#pragma unroll
+        for (int s = 0; s < WNS; ++s) {
+            if (s >= ns) break;
+            const size_t row = (stp * WNS + s) * 16 + ix.arow;
+            const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
+            for (int g = ix.g0; g < HP / 4; g += 16) {
+                const int acol = 4 * g;
+                f32x4 dp = f4zero();
+                if (row < rows && acol < H) {
+                    const size_t off = row * H + acol;
+                    const f32x4 hv = ld4(hout + off), dv = ld4(dh + off);
+                    f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (hdc.on) dm = drop_mul4(hdc, rh, g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = hv[r] > 0.f ? dv[r] * dm[r] : 0.f;
+                    st4(dpre_stash + off, dp);
+                }
+                st4(&tile[16 * s + ix.arow][acol], dp);
+            }
+        }
+        __syncthreads();
+        // ---- phase B: dh <- dpre W; sums for the BatchNorm backward of the conv layer below (first hidden layer only)
+#pragma unroll 1
+        for (int kk = 0; kk < WKB; ++kk) {
+            const int nb = ix.w + 4 * kk;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const bool cok = bcol < H;
+                f32x4 ntp[WNS];
+                bool rvalid[WNS];
+#pragma unroll
+                for (int s = 0; s < WNS; ++s) {
+                    const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                    rvalid[s] = s < ns && row < rows;
+                    ntp[s] = (do_next && rvalid[s] && cok) ? ld4(next.tmp + row * H + bcol) : f4zero();
+                }
+                f32x4 dv[WNS];
+                wide_gemm_n<0>(tile, ns, rWt, H, NB, nb, ix.rs, ix.q, dv);
+                f32x4 t1 = f4zero(), t2 = f4zero();
+#pragma unroll
+                for (int s = 0; s < WNS; ++s) {
+                    if (rvalid[s] && cok) {
+                        const size_t row = (stp * WNS + s) * 16 + ix.rs;
+                        st4(dh + row * H + bcol, dv[s]);
+                        if (do_next) {
+                            const f32x4 nmu = ld4(&cl[0][bcol]), nrs = ld4(&cl[1][bcol]);
+                            const f32x4 nga = ld4(&cl[2][bcol]), nbe = ld4(&cl[3][bcol]);
+                            f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)row), bcol >> 2);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
+                                const float bn = xh * nga[r] + nbe[r];
+                                const float d = bn > 0.f ? dv[s][r] * dm[r] : 0.f;
+                                t1[r] += d;
+                                t2[r] += d * xh;
+                            }
+                        }
+                    }
+                }
+                if (do_next) wide_acc_cols(nacc, bcol, ix.rs == 0 && cok, t1, t2);
+            }
+        }
+        __syncthreads();
+    }
+    if (do_next) {
+#pragma unroll
+        for (int k = 0; k < WKB; ++k) {
+            const int nb = ix.w + 4 * k;
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (nb < NB && ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+                st4(next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nacc[0][bcol]));
+                st4(next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nacc[1][bcol]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-channel sums over rows for any H, one partial row per workgroup:
 //   BNSTATS: partial[block][2][H] = sum(dbn), sum(dbn * xhat) of a BatchNorm backward (as k_bn_bwd_stats)
 //   else   : partial[block][H]    = sum_row g[row][h] * scale[row / C]         (edge-embedding gradient)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, load_golden
+from conftest import report, golden_files, load_golden
 from oracle import gcn_oracle
 
 pytestmark = pytest.mark.gpu
@@ -269,7 +269,10 @@ def test_wide_layer_many_steps_per_workgroup():
                                                  (16, 30, 2, 2), (32, 17, 3, 2),
                                                  # corner cases of the backward schedule: one or two layers, no hidden
                                                  # MLP layer, the deepest MLP, the edge-score head
-                                                 (16, 1, 1, 2), (32, 2, 1, 1), (64, 3, 4, 2), (8, 1, 2, 1), (64, 2, 3, 2)])
+                                                 (16, 1, 1, 2), (32, 2, 1, 1), (64, 3, 4, 2), (8, 1, 2, 1), (64, 2, 3, 2),
+                                                 # MLPs with two and three hidden layers above 64 channels: the hidden
+                                                 # layers before the last run as launches of their own
+                                                 (80, 2, 3, 2), (96, 2, 4, 2), (72, 2, 3, 1), (300, 1, 3, 2)])
 def test_wide_model_matches_oracle(H, L, mlp_layers, voc):
     """Whole model (embedding, L layers, edge MLP, loss) against the oracle in float64: hidden sizes above 64, and
     stacks deeper than 15 layers (the 30 of the large synthetic configuration)."""
@@ -332,6 +335,65 @@ def test_wide_model_matches_oracle(H, L, mlp_layers, voc):
     gmax = max(float(g.abs().max()) for g in ref.values())
     for k, p in model.named_parameters():
         assert_close(p.grad, ref[k], "grad " + k, atol=1e-6 * gmax)
+
+
+@pytest.mark.parametrize("H,mlp_layers", [(96, 4), (80, 3), (48, 4)])
+def test_deep_mlp_train_mode_gradient_is_the_derivative_of_the_forward(H, mlp_layers):
+    """Dropout in a head with several hidden layers: with the generators restarted before every forward pass the masks
+    repeat, the training-mode loss is a fixed function of the parameters, and the gradient the backward pass returns
+    must be its derivative (central differences along random directions in a hidden-layer weight of the MLP and along the
+    gradient of the scale of the last conv layer's edge BatchNorm).  A backward pass that regenerated another mask than the forward pass used fails by far."""
+    from src.common.synthetic import make_batch
+    from src.gcn.hip import lib as L
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    dev = _dev()
+    B, V, C = 2, 7, 3
+    batch = make_batch(B, V, C, "random", 1000, 5000, 5, 500, seed=5)
+    cfg = _Cfg(num_nodes=V, num_commodities=C, voc_edges_in=3, voc_edges_out=2, hidden_dim=H, num_layers=2,
+               mlp_layers=mlp_layers, aggregation="mean", dropout_rate=0.25)
+    torch.manual_seed(3)
+    model = ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(dev).train()
+    cap = torch.from_numpy(batch["edges_capacity"]).to(dev)
+    comm = torch.from_numpy(batch["commodities"]).to(dev)
+    nodes = torch.from_numpy(batch["nodes"]).to(dev)
+    y_edges = torch.from_numpy(batch["edges_target"]).to(dev)
+    x_edges = (cap > 0).long()
+
+    def loss_of():
+        L.reseed(seed=77)
+        return model(x_edges, comm, cap, nodes, y_edges, batch["edge_cw"])[1]
+
+    l0 = loss_of()
+    l0.backward()
+    l1 = loss_of()
+    assert float(l0.detach()) == float(l1.detach())     # same masks after a restart
+    L.reseed(seed=78)
+    assert float(model(x_edges, comm, cap, nodes, y_edges, batch["edge_cw"])[1].detach()) != float(l0.detach())
+    names = dict(model.named_parameters())
+    for key in ("mlp_edges.layers.0.weight", f"mlp_edges.layers.{3 * (mlp_layers - 2)}.weight",
+                # scale of the last conv layer's edge BatchNorm: its gradient is one of the sums the first hidden
+                # layer's backward launch accumulates (the shift starts at zero, where the ReLU kinks are dense and
+                # central differences are off by tens of percent with any kernel)
+                "gcn_layers.1.bn_edge.batch_norm.weight"):
+        prm = names[key]
+        g = prm.grad.clone()
+        if key.startswith("mlp_edges"):
+            gen = torch.Generator().manual_seed(1)
+            dirn = torch.randn(prm.shape, generator=gen).to(dev)
+        else:
+            dirn = g.clone()         # along the gradient: the largest derivative, well above the float32 noise of the loss
+        dirn = dirn / dirn.norm()
+        eps = 2e-3 * max(float(prm.detach().norm()), 1.0)
+        with torch.no_grad():
+            prm.add_(eps * dirn)
+            lp = float(loss_of().detach().double())
+            prm.sub_(2 * eps * dirn)
+            lm = float(loss_of().detach().double())
+            prm.add_(eps * dirn)
+        fd, an = (lp - lm) / (2 * eps), float((g * dirn).sum())
+        report(f"[deep mlp train H={H} mlp_layers={mlp_layers}] {key}: directional derivative {an:.5e}, central difference {fd:.5e}")
+        assert abs(fd - an) <= 0.08 * max(abs(an), abs(fd)) + 1e-4, (key, fd, an)   # the loss has ReLU kinks: a few percent of curvature error
+    L.reseed()
 
 
 def test_wide_layer_train_mode_is_consistent():
