@@ -796,6 +796,11 @@ extern "C" int gcn_phase_trace_read(unsigned long long* host_out /* [512] */) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_trace), 512 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef GCN_PHASE_ACC
+extern "C" int gcn_phase_acc_read(unsigned long long* host_out /* [1024][4][8] */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 1024 * 4 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 const char* gcn_last_error(void) { return g_err; }
 
 static void prof_clear() {

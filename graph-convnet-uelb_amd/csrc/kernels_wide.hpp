@@ -254,6 +254,32 @@ __device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int 
     }
 }
 
+// Phase accounting (measurement builds, -DGCN_PHASE_ACC=1 forward / =2 backward edge kernel): every wavefront adds up
+// the shader-clock cycles it spends in each phase of its steps over the whole launch; g_phase_acc[workgroup][wavefront][slot].
+#ifdef GCN_PHASE_ACC
+__device__ unsigned long long g_phase_acc[1024][4][8];
+#define GCN_ACC_DECL unsigned long long pa_t_ = clock64(), pa_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GCN_ACC(slot) do { const unsigned long long n_ = clock64(); pa_[slot] += n_ - pa_t_; pa_t_ = n_; } while (0)
+#define GCN_ACC_END(w, lane) do { if ((lane) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_phase_acc[blockIdx.x][w][k_] = pa_[k_]; } while (0)
+#endif
+#if defined(GCN_PHASE_ACC) && GCN_PHASE_ACC == 1
+#define ACCF_DECL GCN_ACC_DECL
+#define ACCF(slot) GCN_ACC(slot)
+#define ACCF_END(w, lane) GCN_ACC_END(w, lane)
+#else
+#define ACCF_DECL do { } while (0)
+#define ACCF(slot) do { } while (0)
+#define ACCF_END(w, lane) do { } while (0)
+#endif
+#if defined(GCN_PHASE_ACC) && GCN_PHASE_ACC == 2
+#define ACCB_DECL GCN_ACC_DECL
+#define ACCB(slot) GCN_ACC(slot)
+#define ACCB_END(w, lane) GCN_ACC_END(w, lane)
+#else
+#define ACCB_DECL do { } while (0)
+#define ACCB(slot) do { } while (0)
+#define ACCB_END(w, lane) do { } while (0)
+#endif
 // phase stamps (GCN_PHASE_TRACE builds): the forward kernel writes the trace unless GCN_TRACE_BWD selects the backward one
 #ifdef GCN_TRACE_BWD
 #define GCN_STAMP_F(slot) do { } while (0)
@@ -292,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
     int tstep = 0;
 #endif
     __syncthreads();
+    ACCF_DECL;
     for (int u = u0; u < u1; ++u) {
         const int bi = u / C, c = u - bi * C, b = bi / V;
         f32x4 num[WKB], den[WKB];
@@ -351,7 +378,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                 }
             }
             GCN_STAMP_F(1);
+            ACCF(0);
             __syncthreads();
+            ACCF(1);
             GCN_STAMP_F(2);
             {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
 #pragma unroll 1
@@ -373,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                         f32x4 et2[WNS];
                         wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2);
                         if (kk == 0) GCN_STAMP_F(3);
+                        ACCF(2);
                         f32x4 t1 = f4zero(), t2 = f4zero();
                         if (cok) {
 #pragma unroll
@@ -395,13 +425,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                             }
                         }
                         wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
+                        ACCF(3);
                     }
                     if (kk == 0) GCN_STAMP_F(4);
                     rot(num); rot(den);
                 }
             }
             GCN_STAMP_F(5);
+            ACCF(4);
             __syncthreads();
+            ACCF(5);
             GCN_STAMP_F(6);
 #ifdef GCN_PHASE_TRACE
             ++tstep;
@@ -444,6 +477,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
             }
         }
     }
+    ACCF(6);
+    ACCF_END(ix.w, ix.lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -483,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
     int tstep = 0;
 #endif
     __syncthreads();
+    ACCB_DECL;
     for (int u = u0; u < u1; ++u) {
         int tt = u;
         const int c = tt % C; tt /= C;
@@ -543,7 +579,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                 st4(&qa[s][0][acol], qv);
                 st4(&qa[s][1][acol], ai);
             }
+            ACCB(0);
             __syncthreads();
+            ACCB(1);
             GCN_STAMP_B(1);
             // ---- phase A
 #pragma unroll
@@ -588,7 +626,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                 }
             }
             GCN_STAMP_B(2);
+            ACCB(2);
             __syncthreads();
+            ACCB(3);
             GCN_STAMP_B(3);
             {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
                 const int jb = jt * 16 + ix.rs;
@@ -617,6 +657,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                         f32x4 o2[WNS];
                         wide_gemm_n<GCN_WIDE_PIPE_B>(tdet, ns, rW, H, NB, nb, ix.rs, ix.q, o2);
                         if (kk == 0) GCN_STAMP_B(4);
+                        ACCB(4);
                         f32x4 t1 = f4zero(), t2 = f4zero();
 #pragma unroll
                         for (int s = 0; s < WNS; ++s) {
@@ -645,11 +686,14 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
                             if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i0 + (size_t)s * C) * H + bcol, rsum);
                         }
                         if (do_next) wide_acc_cols(nss, bcol, ix.rs == 0 && bcol < H, t1, t2);
+                        ACCB(5);
                     }
                 }
             }
             GCN_STAMP_B(5);
+            ACCB(6);
             __syncthreads();
+            ACCB(7);
             GCN_STAMP_B(6);
 #ifdef GCN_PHASE_TRACE
             ++tstep;
@@ -679,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
             }
         }
     }
+    ACCB_END(ix.w, ix.lane);
 }
 
 // ------------------------------------------------------------------------------------------------
