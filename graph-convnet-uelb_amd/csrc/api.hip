@@ -1390,13 +1390,17 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
 
 // ---- beam search ---------------------------------------------------------------------------------
 // workspace: working capacities [B][V][V] (strict mode when they do not fit LDS), then the speculative
-// per-commodity results: lengths [B][C] and paths [B][C][max(V, 10)]
-size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
-    (void)K;
-    if (B <= 0 || V <= 0 || C <= 0) return 0;
+// per-commodity results: lengths [B][C] and paths [B][C][max(V, 10)], then (large K x V only) the adjacency lists:
+// row pointers [B][V + 1], columns and rows [B][nnzc] (beam_adj_capacity)
+static size_t beam_ws_base_bytes(int B, int V, int C) {
     const int PL = V > 10 ? V : 10;
     return align_up((size_t)B * V * V * sizeof(float)) + align_up((size_t)B * C * sizeof(int)) +
            align_up((size_t)B * C * PL * sizeof(int));
+}
+size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
+    if (B <= 0 || V <= 0 || C <= 0) return 0;
+    const size_t nnzc = K > 0 ? (size_t)beam_adj_capacity(V, K) : 0;
+    return beam_ws_base_bytes(B, V, C) + (nnzc ? align_up((size_t)B * (V + 1) * sizeof(int)) + 2 * align_up((size_t)B * nnzc * sizeof(unsigned short)) : 0);
 }
 
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
@@ -1413,37 +1417,52 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
     const bool strict = mode_strict && algorithm != BEAM_ALGO_UNCONSTRAINED;
     int cap_in_lds = strict && ((size_t)V * V * sizeof(float) <= 32768) ? 1 : 0;
     if (strict && !cap_in_lds) {
-        if (!ws || ws_bytes < gcn_beam_ws_bytes(B, V, C, K)) return fail(-2, "gcn_beam_search: workspace too small");
+        if (!ws || ws_bytes < align_up((size_t)B * V * V * sizeof(float))) return fail(-2, "gcn_beam_search: workspace too small");
     }
-    const size_t lds = beam_lds_bytes(V, K, cap_in_lds);
+    // adjacency lists (large K x V): only with the full workspace, and only if they fit LDS beside the beam state
+    hipStream_t st = (hipStream_t)stream;
+    int nnzc = beam_adj_capacity(V, K);
+    if (!ws || ws_bytes < gcn_beam_ws_bytes(B, V, C, K) || beam_lds_bytes(V, K, cap_in_lds, nnzc) > 64 * 1024) nnzc = 0;
+    int* adj_ptr = nullptr;
+    unsigned short *adj_col = nullptr, *adj_row = nullptr;
+    if (nnzc) {
+        char* base = (char*)ws + beam_ws_base_bytes(B, V, C);
+        adj_ptr = (int*)base; base += align_up((size_t)B * (V + 1) * sizeof(int));
+        adj_col = (unsigned short*)base; base += align_up((size_t)B * nnzc * sizeof(unsigned short));
+        adj_row = (unsigned short*)base;
+        GCN_PROF_PRE("k_beam_adjacency");
+        k_beam_adjacency<<<B, 256, 0, st>>>(V, nnzc, cap, adj_ptr, adj_col, adj_row);
+        GCN_CHECK_LAUNCH("k_beam_adjacency");
+    }
+    const size_t lds = beam_lds_bytes(V, K, cap_in_lds, nnzc);
     if (lds > 160 * 1024) return fail(-1, "gcn_beam_search: beam state of %zu bytes exceeds the 160 KiB LDS (V=%d, K=%d)", lds, V, K);
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(-3, "gcn_beam_search: cannot raise the dynamic LDS limit to %zu bytes", lds);
     }
     const int jobs = algorithm == BEAM_ALGO_UNCONSTRAINED ? B * C : B;
-    hipStream_t st = (hipStream_t)stream;
     // speculative pass over all (graph, commodity) pairs, when the workspace has room for its results
     int *spec_len = nullptr, *spec_paths = nullptr;
-    if (algorithm != BEAM_ALGO_UNCONSTRAINED && ws && ws_bytes >= gcn_beam_ws_bytes(B, V, C, K)) {
+    if (algorithm != BEAM_ALGO_UNCONSTRAINED && ws && ws_bytes >= beam_ws_base_bytes(B, V, C)) {
         char* base = (char*)ws + align_up((size_t)B * V * V * sizeof(float));
         spec_len = (int*)base;
         spec_paths = (int*)(base + align_up((size_t)B * C * sizeof(int)));
         int spec_cap_lds = (size_t)V * V * sizeof(float) <= 32768 ? 1 : 0;
-        if (beam_lds_bytes(V, K, spec_cap_lds) > 160 * 1024) spec_cap_lds = 0;
-        const size_t slds = beam_lds_bytes(V, K, spec_cap_lds);
+        if (beam_lds_bytes(V, K, spec_cap_lds, nnzc) > 160 * 1024) spec_cap_lds = 0;
+        const size_t slds = beam_lds_bytes(V, K, spec_cap_lds, nnzc);
         if (slds > 48 * 1024) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_beam_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
                 return fail(-3, "gcn_beam_search: cannot raise the dynamic LDS limit to %zu bytes", slds);
         }
         GCN_PROF_PRE("k_beam_spec");
-        k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths, spec_len);
+        k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths, spec_len,
+                                             adj_ptr, adj_col, nnzc);
         GCN_CHECK_LAUNCH("k_beam_spec");
     }
     GCN_PROF_PRE("k_beam_search");
     k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, strict ? 1 : 0, max_iter, y, cap, comm, perms,
                                                           n_perms, perm_start, run_mask, (float*)ws, cap_in_lds, paths, path_len,
-                                                          feasible, attempts, spec_paths, spec_len);
+                                                          feasible, attempts, spec_paths, spec_len, adj_ptr, adj_col, adj_row, nnzc);
     GCN_CHECK_LAUNCH("k_beam_search");
     return 0;
 }

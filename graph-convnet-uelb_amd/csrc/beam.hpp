@@ -78,7 +78,8 @@ __device__ __forceinline__ BeamCand beam_wave_best_dpp(BeamCand c) {
 
 // LDS carve (bytes), all regions 16-byte aligned:
 //   cand_score float[K*V] | cand_ok u8[K*V] | path u16[2][K][V] | visited u32[2][K][VW] |
-//   beam_node int[2][K] | beam_score float[2][K] | best_path u16[V] | wcap float[V*V] (optional)
+//   beam_node int[2][K] | beam_score float[2][K] | best_path u16[V] | wcap float[V*V] (optional) |
+//   adjacency (optional): off int[K+1] | adj_ptr int[V+1] | adj_col u16[nnzc]
 struct BeamLds {
     float* cand_score;
     unsigned char* cand_ok;
@@ -88,11 +89,19 @@ struct BeamLds {
     float* beam_score;
     unsigned short* best_path;
     float* wcap;
+    int* off;                   // first compact candidate of every beam (adjacency lists in use)
+    int* adj_ptr;               // CSR of the graph's edges with non-zero initial capacity, columns ascending; nullptr = not in use
+    unsigned short* adj_col;
 };
 
 __host__ __device__ inline size_t beam_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds) {
+// Adjacency lists pay when the dense candidate grid K x V does not fit the registers of a wavefront; they hold up to
+// 24 edges per node on average (denser graphs, or more than 2048 nodes, keep the dense scan).
+__host__ __device__ inline int beam_adj_capacity(int V, int K) {
+    return (K * V > 64 * BEAM_CPL && K <= 64 && V <= 2048) ? 24 * V : 0;
+}
+__host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds, int nnzc = 0) {
     const int VW = (V + 31) / 32;
     size_t s = 0;
     s += beam_align16((size_t)K * V * 4);
@@ -103,10 +112,11 @@ __host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds) {
     s += beam_align16((size_t)2 * K * 4);
     s += beam_align16((size_t)V * 2);
     if (cap_in_lds) s += beam_align16((size_t)V * V * 4);
+    if (nnzc) s += beam_align16((size_t)(K + 1) * 4) + beam_align16((size_t)(V + 1) * 4) + beam_align16((size_t)nnzc * 2);
     return s;
 }
 
-__device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds) {
+__device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds, int nnzc = 0) {
     const int VW = (V + 31) / 32;
     BeamLds l;
     l.cand_score = (float*)base; base += beam_align16((size_t)K * V * 4);
@@ -117,7 +127,60 @@ __device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds) {
     l.beam_score = (float*)base; base += beam_align16((size_t)2 * K * 4);
     l.best_path = (unsigned short*)base; base += beam_align16((size_t)V * 2);
     l.wcap = cap_in_lds ? (float*)base : nullptr;
+    if (cap_in_lds) base += beam_align16((size_t)V * V * 4);
+    l.off = nullptr; l.adj_ptr = nullptr; l.adj_col = nullptr;
+    if (nnzc) {
+        l.off = (int*)base; base += beam_align16((size_t)(K + 1) * 4);
+        l.adj_ptr = (int*)base; base += beam_align16((size_t)(V + 1) * 4);
+        l.adj_col = (unsigned short*)base;
+    }
     return l;
+}
+
+// The graph's adjacency lists from global memory into LDS; returns the number of edges, or -1 when the lists are not
+// available (no workspace, or the graph has more edges than the lists hold): the caller then clears L.adj_ptr.
+__device__ inline int beam_load_adjacency(BeamLds& L, const int* __restrict__ gptr, const unsigned short* __restrict__ gcol, int V) {
+    const int lane = threadIdx.x;
+    const int nnz = (L.adj_ptr != nullptr && gptr != nullptr) ? gptr[V] : -1;
+    if (nnz < 0) { L.adj_ptr = nullptr; L.adj_col = nullptr; return -1; }
+    for (int t = lane; t <= V; t += 64) L.adj_ptr[t] = gptr[t];
+    for (int t = lane; t < nnz; t += 64) L.adj_col[t] = gcol[t];
+    __syncthreads();
+    return nnz;
+}
+
+// CSR of the edges with non-zero capacity, one workgroup per graph: adj_ptr [B][V + 1] (entry V = number of edges, or
+// -1 if they exceed nnzc), adj_col / adj_row [B][nnzc] with the columns of every row ascending.  V <= 2048.
+__global__ __launch_bounds__(256) void k_beam_adjacency(int V, int nnzc, const float* __restrict__ cap, int* __restrict__ adj_ptr,
+                                                       unsigned short* __restrict__ adj_col, unsigned short* __restrict__ adj_row) {
+    __shared__ int cnt[2049];
+    const int b = blockIdx.x;
+    const float* cb = cap + (size_t)b * V * V;
+    for (int r = threadIdx.x; r < V; r += blockDim.x) {
+        int n = 0;
+        for (int j = 0; j < V; ++j) n += cb[(size_t)r * V + j] != 0.f ? 1 : 0;
+        cnt[r + 1] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt[0] = 0;
+        for (int r = 0; r < V; ++r) cnt[r + 1] += cnt[r];
+    }
+    __syncthreads();
+    const int total = cnt[V];
+    int* pb = adj_ptr + (size_t)b * (V + 1);
+    for (int r = threadIdx.x; r < V; r += blockDim.x) pb[r] = cnt[r];
+    if (threadIdx.x == 0) pb[V] = total <= nnzc ? total : -1;
+    if (total > nnzc) return;
+    for (int r = threadIdx.x; r < V; r += blockDim.x) {
+        int o = cnt[r];
+        for (int j = 0; j < V; ++j)
+            if (cb[(size_t)r * V + j] != 0.f) {
+                adj_col[(size_t)b * nnzc + o] = (unsigned short)j;
+                adj_row[(size_t)b * nnzc + o] = (unsigned short)r;
+                ++o;
+            }
+    }
 }
 
 // One commodity.  capm: [V][V] capacities valid at the start of this commodity (LDS or global).
@@ -159,18 +222,43 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
         unsigned short* npath = L.path + (size_t)ngen * K * V;
         unsigned int* nvis = L.visited + (size_t)ngen * K * VW;
         int nnb = 0;
-        if (K * V <= 64 * BEAM_CPL) {
-            // candidates stay in registers (lane owns idx = lane + 64 j); no LDS traffic and no barrier per round
+        // With adjacency lists the candidates of a step are the out-edges of the beams' nodes, in the same (beam rank,
+        // neighbour ascending) order as the dense grid and with the same index k * V + n for the tie-break: every other
+        // entry of the grid fails the capacity test anyway.  total = their number.
+        int total = -1;
+        if (L.adj_ptr != nullptr) {
+            int inc = 0;
+            if (lane < nb) { const int node = gnode[lane]; inc = node == dst ? 0 : L.adj_ptr[node + 1] - L.adj_ptr[node]; }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+            if (lane < nb) L.off[lane + 1] = inc;
+            if (lane == 0) L.off[0] = 0;
+            __syncthreads();
+            total = L.off[nb];
+            if (total == 0) break;
+        }
+        if (K * V <= 64 * BEAM_CPL || (total >= 0 && total <= 64 * BEAM_CPL)) {
+            // candidates stay in registers (a lane owns four of them); no LDS traffic and no barrier per round
             float cs[BEAM_CPL];
             bool ck[BEAM_CPL];
+            int cidx[BEAM_CPL];
             int any = 0;
 #pragma unroll
             for (int j = 0; j < BEAM_CPL; ++j) {
-                const int idx = lane + 64 * j;
-                bool ok = idx < ncand;
+                const int ci = lane + 64 * j;
+                bool ok = ci < (total >= 0 ? total : ncand);
                 float sc = 0.f;
+                int idx = -1;
                 if (ok) {
-                    const int k = idx / V, n = idx - k * V;
+                    int k, n;
+                    if (total >= 0) {
+                        k = 0;
+                        while (k + 1 < nb && ci >= L.off[k + 1]) ++k;
+                        n = L.adj_col[L.adj_ptr[gnode[k]] + ci - L.off[k]];
+                    } else {
+                        k = ci / V; n = ci - k * V;
+                    }
+                    idx = k * V + n;
                     const int node = gnode[k];
                     ok = node != dst && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
                     if (ok) {
@@ -179,7 +267,7 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                         if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
                     }
                 }
-                cs[j] = sc; ck[j] = ok;
+                cs[j] = sc; ck[j] = ok; cidx[j] = idx;
                 any |= ok ? 1 : 0;
             }
             if (!__any(any)) break;
@@ -190,7 +278,7 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                 for (int j = 0; j < BEAM_CPL; ++j) {
                     if (ck[j]) {
                         BeamCand o;
-                        o.idx = lane + 64 * j; o.score = cs[j];
+                        o.idx = cidx[j]; o.score = cs[j];
                         if (beam_better(o, c)) c = o;
                     }
                 }
@@ -198,7 +286,7 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                 if (c.idx < 0) break;
 #pragma unroll
                 for (int j = 0; j < BEAM_CPL; ++j)
-                    if (lane + 64 * j == c.idx) ck[j] = false;
+                    if (cidx[j] == c.idx) ck[j] = false;
                 const int k = c.idx / V, n = c.idx - k * V;
                 if (lane == 0) {
                     L.beam_node[ngen * K + r] = n;
@@ -273,14 +361,17 @@ __global__ __launch_bounds__(64) void k_beam_search(
     const float* __restrict__ cap, const long long* __restrict__ comm, const int* __restrict__ perms, int n_perms,
     const int* __restrict__ perm_start, const unsigned char* __restrict__ run_mask, float* __restrict__ capws,
     int cap_in_lds, int* __restrict__ paths, int* __restrict__ path_len, int* __restrict__ feasible,
-    int* __restrict__ attempts, const int* __restrict__ spec_paths, const int* __restrict__ spec_len) {
+    int* __restrict__ attempts, const int* __restrict__ spec_paths, const int* __restrict__ spec_len,
+    const int* __restrict__ adj_ptr, const unsigned short* __restrict__ adj_col, const unsigned short* __restrict__ adj_row,
+    int nnzc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
-    const BeamLds L = beam_carve(smem, V, K, cap_in_lds && strict && algo != BEAM_ALGO_UNCONSTRAINED);
+    BeamLds L = beam_carve(smem, V, K, cap_in_lds && strict && algo != BEAM_ALGO_UNCONSTRAINED, nnzc);
     if (algo == BEAM_ALGO_UNCONSTRAINED) {
         const int b = blockIdx.x / C, c = blockIdx.x - b * C;
         if (run_mask && !run_mask[b]) return;
+        beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
         const long long* cm = comm + ((size_t)b * C + c) * 3;
         const int len = beam_commodity(L, cap + (size_t)b * V * V, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0],
                                        (int)cm[1], 0.f, 0);
@@ -296,6 +387,8 @@ __global__ __launch_bounds__(64) void k_beam_search(
     if (run_mask && !run_mask[b]) return;
     if (algo == BEAM_ALGO_GREEDY) K = 1;
     const float* cap_b = cap + (size_t)b * V * V;
+    const int nnz = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
+    const unsigned short* rows_b = adj_row ? adj_row + (size_t)b * nnzc : nullptr;
     float* wcap = strict ? (L.wcap ? L.wcap : capws + (size_t)b * V * V) : nullptr;
     const float* yb = y + (size_t)b * V * V * C;
     const long long* cm = comm + (size_t)b * C * 3;
@@ -325,9 +418,17 @@ __global__ __launch_bounds__(64) void k_beam_search(
             bool reuse = spec_len != nullptr;
             if (reuse && strict) {
                 int diff = 0;
-                for (int t = lane; t < V * V; t += 64) {
-                    const float c0 = cap_b[t], c1 = wcap[t];
-                    diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
+                if (nnz >= 0) {         // edges without initial capacity are never used: only the listed ones can differ
+                    for (int e = lane; e < nnz; e += 64) {
+                        const int t = (int)rows_b[e] * V + (int)L.adj_col[e];
+                        const float c0 = cap_b[t], c1 = wcap[t];
+                        diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
+                    }
+                } else {
+                    for (int t = lane; t < V * V; t += 64) {
+                        const float c0 = cap_b[t], c1 = wcap[t];
+                        diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
+                    }
                 }
                 reuse = !__any(diff);
             }
@@ -371,15 +472,17 @@ __global__ __launch_bounds__(64) void k_beam_search(
 __global__ __launch_bounds__(64) void k_beam_spec(
     int B, int V, int C, int K, int algo, const float* __restrict__ y, const float* __restrict__ cap,
     const long long* __restrict__ comm, const unsigned char* __restrict__ run_mask, int cap_in_lds,
-    int* __restrict__ spec_paths, int* __restrict__ spec_len) {
+    int* __restrict__ spec_paths, int* __restrict__ spec_len, const int* __restrict__ adj_ptr,
+    const unsigned short* __restrict__ adj_col, int nnzc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
-    const BeamLds L = beam_carve(smem, V, K, cap_in_lds);
+    BeamLds L = beam_carve(smem, V, K, cap_in_lds, nnzc);
     const int b = blockIdx.x / C, c = blockIdx.x - b * C;
     if (run_mask && !run_mask[b]) return;
     if (algo == BEAM_ALGO_GREEDY) K = 1;
     const float* cap_b = cap + (size_t)b * V * V;
+    beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
     if (L.wcap) {
         for (int t = lane; t < V * V; t += 64) L.wcap[t] = cap_b[t];
         __syncthreads();

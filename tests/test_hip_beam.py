@@ -125,6 +125,43 @@ def test_beam_matches_c_oracle_at_benchmark_sizes(algo, strict, V, C, K, B):
         assert int(a.attempts.sum()) == used
 
 
+@pytest.mark.parametrize("V,density,K,C,B,strict", [(40, 0.8, 10, 6, 6, True), (60, 0.33, 16, 5, 4, True),
+                                                      (60, 0.33, 16, 5, 4, False), (48, 1.0, 8, 4, 3, True)])
+def test_beam_dense_graphs_match_c_oracle(V, density, K, C, B, strict):
+    """Graphs that are not sparse.  The kernels examine the beams' out-edges through adjacency lists when the dense
+    K x V candidate grid exceeds a wavefront's registers; these cases cover what lies beside that path: graphs with more
+    edges than the lists hold (density 0.8 and 1.0: the dense grid in LDS), and graphs whose lists are in use but whose
+    beams together have more than 256 out-edges in some steps and fewer in others (density 0.33 at K = 16), so that
+    one search alternates between the two."""
+    dev = _dev()
+    rng = np.random.default_rng(V * 7 + K)
+    cap = np.zeros((B, V, V), np.float32)
+    for b in range(B):
+        m = np.triu(rng.random((V, V)) < density, 1)
+        m = m | m.T
+        ring = np.arange(V)
+        m[ring, (ring + 1) % V] = True
+        m[(ring + 1) % V, ring] = True
+        c = np.triu(rng.integers(300, 3000, size=(V, V)).astype(np.float32), 1)
+        cap[b] = (c + c.T) * m
+    comm = np.zeros((B, C, 3), np.int64)
+    for b in range(B):
+        pairs = set()
+        while len(pairs) < C:
+            s_, t_ = (int(v) for v in rng.integers(0, V, size=2))
+            if s_ != t_:
+                pairs.add((s_, t_))
+        comm[b] = np.asarray(sorted((s_, t_, int(rng.integers(5, 500))) for s_, t_ in pairs))
+    y = np.log(rng.random((B, V, V, C)).astype(np.float32) * 0.98 + 0.01).astype(np.float32)
+    y[rng.random(y.shape) < 0.2] = np.float32(-0.5)      # ties
+    rp, rl, rf, _, _ = beam_oracle_c.search(y, cap, comm, K, "deterministic", strict, 5)
+    a = _make("deterministic", y, cap, comm, K, strict, 5, dev)
+    a.search()
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+
+
 @pytest.mark.parametrize("algo,V,C,K,B,seed", [("deterministic", 14, 10, 10, 30, 1), ("standard", 14, 20, 10, 30, 2),
                                                ("greedy", 14, 10, 10, 30, 3), ("deterministic", 40, 12, 5, 10, 4),
                                                ("standard", 100, 6, 4, 4, 5)])
