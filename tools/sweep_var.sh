@@ -1,6 +1,9 @@
 #!/bin/bash
 # Graph-replay bench of one configuration under several settings of one tuning variable.
+# The GCN_TUNE_* variables are read only by the measurement build of the library (tools/build_tuning_lib.sh), which this
+# script selects unless GCN_UELB_LIB already names another build.
 # Usage: bash tools/sweep_var.sh <config> <VAR> <value> [<value> ...]
+export GCN_UELB_LIB=${GCN_UELB_LIB:-$PWD/graph-convnet-uelb_amd/lib/libgcn_uelb_hip_tuning.so}
 cfg=$1; var=$2; shift 2
 mkdir -p gpurun_out
 for g in "$@"; do
