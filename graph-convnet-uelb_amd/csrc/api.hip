@@ -1391,7 +1391,7 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
 // ---- beam search ---------------------------------------------------------------------------------
 // workspace: working capacities [B][V][V] (strict mode when they do not fit LDS), then the speculative
 // per-commodity results: lengths [B][C] and paths [B][C][max(V, 10)], then (large K x V only) the adjacency lists:
-// row pointers [B][V + 1], columns and rows [B][nnzc] (beam_adj_capacity)
+// row pointers [B][V + 1], columns and rows [B][nnzc] (beam_adj_capacity), and the scores gathered per list entry [B][C][nnzc]
 static size_t beam_ws_base_bytes(int B, int V, int C) {
     const int PL = V > 10 ? V : 10;
     return align_up((size_t)B * V * V * sizeof(float)) + align_up((size_t)B * C * sizeof(int)) +
@@ -1400,7 +1400,8 @@ static size_t beam_ws_base_bytes(int B, int V, int C) {
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
     if (B <= 0 || V <= 0 || C <= 0) return 0;
     const size_t nnzc = K > 0 ? (size_t)beam_adj_capacity(V, K) : 0;
-    return beam_ws_base_bytes(B, V, C) + (nnzc ? align_up((size_t)B * (V + 1) * sizeof(int)) + 2 * align_up((size_t)B * nnzc * sizeof(unsigned short)) : 0);
+    return beam_ws_base_bytes(B, V, C) + (nnzc ? align_up((size_t)B * (V + 1) * sizeof(int)) + 2 * align_up((size_t)B * nnzc * sizeof(unsigned short)) +
+                                                 align_up((size_t)B * C * nnzc * sizeof(float)) : 0);
 }
 
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
@@ -1422,17 +1423,22 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
     // adjacency lists (large K x V): only with the full workspace, and only if they fit LDS beside the beam state
     hipStream_t st = (hipStream_t)stream;
     int nnzc = beam_adj_capacity(V, K);
-    if (!ws || ws_bytes < gcn_beam_ws_bytes(B, V, C, K) || beam_lds_bytes(V, K, cap_in_lds, nnzc) > 64 * 1024) nnzc = 0;
+    if (!ws || ws_bytes < gcn_beam_ws_bytes(B, V, C, K) || beam_lds_bytes(V, K, cap_in_lds, nnzc) > 96 * 1024) nnzc = 0;
     int* adj_ptr = nullptr;
     unsigned short *adj_col = nullptr, *adj_row = nullptr;
+    float* y_e = nullptr;
     if (nnzc) {
         char* base = (char*)ws + beam_ws_base_bytes(B, V, C);
         adj_ptr = (int*)base; base += align_up((size_t)B * (V + 1) * sizeof(int));
         adj_col = (unsigned short*)base; base += align_up((size_t)B * nnzc * sizeof(unsigned short));
-        adj_row = (unsigned short*)base;
+        adj_row = (unsigned short*)base; base += align_up((size_t)B * nnzc * sizeof(unsigned short));
+        y_e = (float*)base;
         GCN_PROF_PRE("k_beam_adjacency");
         k_beam_adjacency<<<B, 256, 0, st>>>(V, nnzc, cap, adj_ptr, adj_col, adj_row);
         GCN_CHECK_LAUNCH("k_beam_adjacency");
+        GCN_PROF_PRE("k_beam_gather_y");
+        k_beam_gather_y<<<dim3(B, 64, 1), 256, 0, st>>>(V, C, nnzc, y, adj_ptr, adj_col, adj_row, y_e);
+        GCN_CHECK_LAUNCH("k_beam_gather_y");
     }
     const size_t lds = beam_lds_bytes(V, K, cap_in_lds, nnzc);
     if (lds > 160 * 1024) return fail(-1, "gcn_beam_search: beam state of %zu bytes exceeds the 160 KiB LDS (V=%d, K=%d)", lds, V, K);
@@ -1456,13 +1462,13 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
         }
         GCN_PROF_PRE("k_beam_spec");
         k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths, spec_len,
-                                             adj_ptr, adj_col, nnzc);
+                                             adj_ptr, adj_col, y_e, nnzc);
         GCN_CHECK_LAUNCH("k_beam_spec");
     }
     GCN_PROF_PRE("k_beam_search");
     k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, strict ? 1 : 0, max_iter, y, cap, comm, perms,
                                                           n_perms, perm_start, run_mask, (float*)ws, cap_in_lds, paths, path_len,
-                                                          feasible, attempts, spec_paths, spec_len, adj_ptr, adj_col, adj_row, nnzc);
+                                                          feasible, attempts, spec_paths, spec_len, adj_ptr, adj_col, adj_row, y_e, nnzc);
     GCN_CHECK_LAUNCH("k_beam_search");
     return 0;
 }

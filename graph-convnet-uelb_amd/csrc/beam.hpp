@@ -77,21 +77,23 @@ __device__ __forceinline__ BeamCand beam_wave_best_dpp(BeamCand c) {
 }
 
 // LDS carve (bytes), all regions 16-byte aligned:
-//   cand_score float[K*V] | cand_ok u8[K*V] | path u16[2][K][V] | visited u32[2][K][VW] |
+//   cand_score float[K*V] | cand_ok u8[K*V] | bp_node u16[V][K] | bp_par u16[V][K] | visited u32[2][K][VW] |
 //   beam_node int[2][K] | beam_score float[2][K] | best_path u16[V] | wcap float[V*V] (optional) |
-//   adjacency (optional): off int[K+1] | adj_ptr int[V+1] | adj_col u16[nnzc]
+//   adjacency (optional): adj_ptr int[V+1] | adj_col u16[nnzc] | cap_e float[nnzc] | y_e float[nnzc]
 struct BeamLds {
     float* cand_score;
     unsigned char* cand_ok;
-    unsigned short* path;
+    unsigned short* bp_node;    // back pointers: node at position t of the beam of rank r at depth t ...
+    unsigned short* bp_par;     // ... and the rank of the beam it extends
     unsigned int* visited;
     int* beam_node;
     float* beam_score;
     unsigned short* best_path;
     float* wcap;
-    int* off;                   // first compact candidate of every beam (adjacency lists in use)
     int* adj_ptr;               // CSR of the graph's edges with non-zero initial capacity, columns ascending; nullptr = not in use
     unsigned short* adj_col;
+    float* cap_e;               // capacities per list entry (the working capacities in strict mode)
+    float* y_e;                 // scores of the current commodity per list entry
 };
 
 __host__ __device__ inline size_t beam_align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -106,13 +108,14 @@ __host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds, i
     size_t s = 0;
     s += beam_align16((size_t)K * V * 4);
     s += beam_align16((size_t)K * V);
-    s += beam_align16((size_t)2 * K * V * 2);
+    s += beam_align16((size_t)K * V * 2);
+    s += beam_align16((size_t)K * V * 2);
     s += beam_align16((size_t)2 * K * VW * 4);
     s += beam_align16((size_t)2 * K * 4);
     s += beam_align16((size_t)2 * K * 4);
     s += beam_align16((size_t)V * 2);
     if (cap_in_lds) s += beam_align16((size_t)V * V * 4);
-    if (nnzc) s += beam_align16((size_t)(K + 1) * 4) + beam_align16((size_t)(V + 1) * 4) + beam_align16((size_t)nnzc * 2);
+    if (nnzc) s += beam_align16((size_t)(V + 1) * 4) + beam_align16((size_t)nnzc * 2) + 2 * beam_align16((size_t)nnzc * 4);
     return s;
 }
 
@@ -121,18 +124,20 @@ __device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds, i
     BeamLds l;
     l.cand_score = (float*)base; base += beam_align16((size_t)K * V * 4);
     l.cand_ok = (unsigned char*)base; base += beam_align16((size_t)K * V);
-    l.path = (unsigned short*)base; base += beam_align16((size_t)2 * K * V * 2);
+    l.bp_node = (unsigned short*)base; base += beam_align16((size_t)K * V * 2);
+    l.bp_par = (unsigned short*)base; base += beam_align16((size_t)K * V * 2);
     l.visited = (unsigned int*)base; base += beam_align16((size_t)2 * K * VW * 4);
     l.beam_node = (int*)base; base += beam_align16((size_t)2 * K * 4);
     l.beam_score = (float*)base; base += beam_align16((size_t)2 * K * 4);
     l.best_path = (unsigned short*)base; base += beam_align16((size_t)V * 2);
     l.wcap = cap_in_lds ? (float*)base : nullptr;
     if (cap_in_lds) base += beam_align16((size_t)V * V * 4);
-    l.off = nullptr; l.adj_ptr = nullptr; l.adj_col = nullptr;
+    l.adj_ptr = nullptr; l.adj_col = nullptr; l.cap_e = nullptr; l.y_e = nullptr;
     if (nnzc) {
-        l.off = (int*)base; base += beam_align16((size_t)(K + 1) * 4);
         l.adj_ptr = (int*)base; base += beam_align16((size_t)(V + 1) * 4);
-        l.adj_col = (unsigned short*)base;
+        l.adj_col = (unsigned short*)base; base += beam_align16((size_t)nnzc * 2);
+        l.cap_e = (float*)base; base += beam_align16((size_t)nnzc * 4);
+        l.y_e = (float*)base;
     }
     return l;
 }
@@ -142,11 +147,43 @@ __device__ inline BeamLds beam_carve(char* base, int V, int K, int cap_in_lds, i
 __device__ inline int beam_load_adjacency(BeamLds& L, const int* __restrict__ gptr, const unsigned short* __restrict__ gcol, int V) {
     const int lane = threadIdx.x;
     const int nnz = (L.adj_ptr != nullptr && gptr != nullptr) ? gptr[V] : -1;
-    if (nnz < 0) { L.adj_ptr = nullptr; L.adj_col = nullptr; return -1; }
+    if (nnz < 0) { L.adj_ptr = nullptr; L.adj_col = nullptr; L.cap_e = nullptr; L.y_e = nullptr; return -1; }
     for (int t = lane; t <= V; t += 64) L.adj_ptr[t] = gptr[t];
     for (int t = lane; t < nnz; t += 64) L.adj_col[t] = gcol[t];
     __syncthreads();
     return nnz;
+}
+
+// Capacities per list entry from a dense [V][V] matrix (lanes over rows).
+__device__ inline void beam_fill_edge_caps(const BeamLds& L, const float* __restrict__ capm, int V) {
+    if (L.cap_e == nullptr) return;
+    for (int r = threadIdx.x; r < V; r += 64)
+        for (int e = L.adj_ptr[r]; e < L.adj_ptr[r + 1]; ++e) L.cap_e[e] = capm[(size_t)r * V + L.adj_col[e]];
+    __syncthreads();
+}
+
+// Scores of one commodity per list entry from the gathered table ye_bc [nnz] into LDS.
+__device__ inline void beam_load_edge_scores(const BeamLds& L, const float* __restrict__ ye_bc, int nnz) {
+    if (L.y_e == nullptr) return;
+    for (int e = threadIdx.x; e < nnz; e += 64) L.y_e[e] = ye_bc[e];
+    __syncthreads();
+}
+
+// y_e [B][C][nnzc]: the scores y[b][row][col][c] of every list entry, gathered once so that a search reads its scores
+// from LDS instead of one scattered cache line per candidate and step.  Grid (B, chunks); consecutive threads take
+// consecutive commodities of one entry (contiguous in y).
+__global__ __launch_bounds__(256) void k_beam_gather_y(int V, int C, int nnzc, const float* __restrict__ y, const int* __restrict__ adj_ptr,
+                                                      const unsigned short* __restrict__ adj_col, const unsigned short* __restrict__ adj_row,
+                                                      float* __restrict__ y_e) {
+    const int b = blockIdx.x;
+    const int nnz = adj_ptr[(size_t)b * (V + 1) + V];
+    if (nnz < 0) return;
+    const size_t n = (size_t)nnz * C;
+    for (size_t t = (size_t)blockIdx.y * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.y * blockDim.x) {
+        const int e = (int)(t / C), c = (int)(t - (size_t)e * C);
+        const int row = adj_row[(size_t)b * nnzc + e], col = adj_col[(size_t)b * nnzc + e];
+        y_e[((size_t)b * C + c) * nnzc + e] = y[(((size_t)b * V + row) * V + col) * C + c];
+    }
 }
 
 // CSR of the edges with non-zero capacity, one workgroup per graph: adj_ptr [B][V + 1] (entry V = number of edges, or
@@ -183,11 +220,24 @@ __global__ __launch_bounds__(256) void k_beam_adjacency(int V, int nnzc, const f
     }
 }
 
-// One commodity.  capm: [V][V] capacities valid at the start of this commodity (LDS or global).
-// yb: y + b*V*V*C + c, element (i, j) at yb[(i*V + j)*C].  Returns the length of the best path
-// (written to L.best_path), 0 if none.  All 64 lanes must call it.
-__device__ inline int beam_commodity(const BeamLds& L, const float* capm, const float* __restrict__ yb, int V, int C,
-                                     int K, int src, int dst, float demand, int check_demand) {
+// Inclusive prefix sum over the lanes of a wavefront (DPP shifts inside each row of 16 lanes, then the row totals).
+__device__ __forceinline__ int beam_wave_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1, lanes shifted in read as 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+    const int row = (int)threadIdx.x >> 4;
+    return x + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+
+// One commodity.  capm: [V][V] capacities valid at the start of this commodity (LDS or global); cap_e (nullable): the
+// same capacities per adjacency-list entry, in LDS.  yb: y + b*V*V*C + c, element (i, j) at yb[(i*V + j)*C].
+// Returns the length of the best path (written to L.best_path), 0 if none.  All 64 lanes must call it.
+// Paths are kept as back pointers: bp_node[t][r] is the node at position t of the beam of rank r at that depth and
+// bp_par[t][r] the rank of the beam it extends; a path is written out only when a beam on the target becomes the result.
+__device__ inline int beam_commodity(const BeamLds& L, const float* capm, const float* cap_e, const float* __restrict__ yb, int V,
+                                     int C, int K, int src, int dst, float demand, int check_demand) {
     const int lane = threadIdx.x;
     const int VW = (V + 31) / 32;
     int gen = 0, nb = 1, len = 1;
@@ -197,52 +247,126 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
     if (lane == 0) {
         L.beam_node[0] = src;
         L.beam_score[0] = 0.f;
-        L.path[0] = (unsigned short)src;
     }
     for (int w = lane; w < VW; w += 64) L.visited[w] = (w == (src >> 5)) ? (1u << (src & 31)) : 0u;
     __syncthreads();
     while (nb > 0) {
-        const unsigned short* gpath = L.path + (size_t)gen * K * V;
         const unsigned int* gvis = L.visited + (size_t)gen * K * VW;
         const int* gnode = L.beam_node + gen * K;
         const float* gscore = L.beam_score + gen * K;
+        // this lane's beam (lanes beyond the queue hold none); K <= 64 whenever the lists or the register path are in use
+        const int my_node = lane < nb ? gnode[lane] : -1;
         // beams on the target become result candidates, in rank order, strict > keeps the earliest
-        for (int r = 0; r < nb; ++r) {
-            if (gnode[r] == dst) {
-                const float s = gscore[r];
-                if (!have_best || s > best_score) {
-                    have_best = true; best_score = s; best_len = len;
-                    for (int t = lane; t < len; t += 64) L.best_path[t] = gpath[(size_t)r * V + t];
+        if (K > 64 || __any(my_node == dst)) {
+            for (int r = 0; r < nb; ++r) {
+                if (gnode[r] == dst) {
+                    const float s = gscore[r];
+                    if (!have_best || s > best_score) {
+                        have_best = true; best_score = s; best_len = len;
+                        if (lane == 0) {
+                            int rr = r;
+                            for (int t = len - 1; t > 0; --t) {
+                                L.best_path[t] = L.bp_node[(size_t)t * K + rr];
+                                rr = L.bp_par[(size_t)t * K + rr];
+                            }
+                            L.best_path[0] = (unsigned short)src;
+                        }
+                    }
                 }
             }
         }
         // expansion: candidate (k, n) in beam-rank order, n ascending
         const int ncand = nb * V;
         const int ngen = gen ^ 1;
-        unsigned short* npath = L.path + (size_t)ngen * K * V;
         unsigned int* nvis = L.visited + (size_t)ngen * K * VW;
         int nnb = 0;
+        // the beam of rank r of the next depth: node n reached from the beam of rank k
+        auto commit = [&](int r, int k, int n, float score) {
+            if (lane == 0) {
+                L.beam_node[ngen * K + r] = n;
+                L.beam_score[ngen * K + r] = score;
+                L.bp_node[(size_t)len * K + r] = (unsigned short)n;
+                L.bp_par[(size_t)len * K + r] = (unsigned short)k;
+            }
+            for (int w = lane; w < VW; w += 64)
+                nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+        };
         // With adjacency lists the candidates of a step are the out-edges of the beams' nodes, in the same (beam rank,
         // neighbour ascending) order as the dense grid and with the same index k * V + n for the tie-break: every other
-        // entry of the grid fails the capacity test anyway.  total = their number.
-        int total = -1;
+        // entry of the grid fails the capacity test anyway.  total = their number; lane k holds the running count
+        // through beam k (inc) and the start of its list (my_ptr).
+        int total = -1, inc = 0, my_ptr = 0;
         if (L.adj_ptr != nullptr) {
-            int inc = 0;
-            if (lane < nb) { const int node = gnode[lane]; inc = node == dst ? 0 : L.adj_ptr[node + 1] - L.adj_ptr[node]; }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-            if (lane < nb) L.off[lane + 1] = inc;
-            if (lane == 0) L.off[0] = 0;
-            __syncthreads();
-            total = L.off[nb];
+            if (my_node >= 0 && my_node != dst) { my_ptr = L.adj_ptr[my_node]; inc = L.adj_ptr[my_node + 1] - my_ptr; }
+            inc = beam_wave_scan(inc);
+            total = __builtin_amdgcn_readlane(inc, 63);
             if (total == 0) break;
         }
-        if (K * V <= 64 * BEAM_CPL || (total >= 0 && total <= 64 * BEAM_CPL)) {
+        if (total >= 0 && total <= 64) {
+            // At most one candidate per lane (the usual case on sparse graphs: K beams x a few out-edges).  A lone
+            // wavefront pays for every instruction it issues, so instead of K rounds of arg-max every candidate counts
+            // the candidates that beat it (score descending, index ascending: the order of the stable sort): that count
+            // is its rank in the next queue, and the first K ranks write their beams side by side.
+            int k = 0, e = 0, node = 0, prev = 0;
+            for (int kb = 0; kb < nb; ++kb) {
+                const int upto = __builtin_amdgcn_readlane(inc, kb), ptr = __builtin_amdgcn_readlane(my_ptr, kb);
+                const int nd = __builtin_amdgcn_readlane(my_node, kb);
+                if (lane >= prev && lane < upto) { k = kb; e = ptr + lane - prev; node = nd; }
+                prev = upto;
+            }
+            bool ok = lane < total;
+            int n = 0, idx = 0x7fffffff;
+            float sc = 0.f;
+            if (ok) {
+                n = L.adj_col[e];
+                idx = k * V + n;
+                const float yv = L.y_e != nullptr ? L.y_e[e] : yb[((size_t)node * V + n) * C];
+                const float cv = cap_e != nullptr ? cap_e[e] : capm[node * V + n];
+                ok = !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u) && (cv != 0.f) && (!check_demand || demand <= cv);
+                sc = gscore[k] + yv;
+            }
+            unsigned long long valid = __ballot(ok);
+            if (valid == 0ull) break;
+            nnb = min(K, (int)__popcll(valid));
+            int rank = 0;
+            while (valid) {
+                const int l = __builtin_ctzll(valid);
+                valid &= valid - 1;
+                const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc), l));
+                const int oi = __builtin_amdgcn_readlane(idx, l);
+                rank += (os > sc || (os == sc && oi < idx)) ? 1 : 0;
+            }
+            if (ok && rank < K) {
+                L.beam_node[ngen * K + rank] = n;
+                L.beam_score[ngen * K + rank] = sc;
+                L.bp_node[(size_t)len * K + rank] = (unsigned short)n;
+                L.bp_par[(size_t)len * K + rank] = (unsigned short)k;
+                for (int w = 0; w < VW; ++w)
+                    nvis[(size_t)rank * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+            }
+        } else if (K * V <= 64 * BEAM_CPL || (total >= 0 && total <= 64 * BEAM_CPL)) {
             // candidates stay in registers (a lane owns four of them); no LDS traffic and no barrier per round
             float cs[BEAM_CPL];
             bool ck[BEAM_CPL];
             int cidx[BEAM_CPL];
             int any = 0;
+            int ck_k[BEAM_CPL], ck_e[BEAM_CPL], ck_node[BEAM_CPL];
+            if (total >= 0) {
+                // beam of every candidate: the first whose running count exceeds its position (uniform loop, scalar broadcasts)
+#pragma unroll
+                for (int j = 0; j < BEAM_CPL; ++j) { ck_k[j] = 0; ck_e[j] = 0; ck_node[j] = 0; }
+                int prev = 0;
+                for (int k = 0; k < nb; ++k) {
+                    const int upto = __builtin_amdgcn_readlane(inc, k), ptr = __builtin_amdgcn_readlane(my_ptr, k);
+                    const int nd = __builtin_amdgcn_readlane(my_node, k);
+#pragma unroll
+                    for (int j = 0; j < BEAM_CPL; ++j) {
+                        const int ci = lane + 64 * j;
+                        if (ci >= prev && ci < upto) { ck_k[j] = k; ck_e[j] = ptr + ci - prev; ck_node[j] = nd; }
+                    }
+                    prev = upto;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < BEAM_CPL; ++j) {
                 const int ci = lane + 64 * j;
@@ -250,22 +374,21 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                 float sc = 0.f;
                 int idx = -1;
                 if (ok) {
-                    int k, n;
+                    int k, n, node;
                     if (total >= 0) {
-                        k = 0;
-                        while (k + 1 < nb && ci >= L.off[k + 1]) ++k;
-                        n = L.adj_col[L.adj_ptr[gnode[k]] + ci - L.off[k]];
+                        k = ck_k[j]; node = ck_node[j];
+                        n = L.adj_col[ck_e[j]];
                     } else {
                         k = ci / V; n = ci - k * V;
+                        node = gnode[k];
                     }
                     idx = k * V + n;
-                    const int node = gnode[k];
+                    // requested beside the capacity, used only if the edge is usable
+                    const float yv = (total >= 0 && L.y_e != nullptr) ? L.y_e[ck_e[j]] : yb[((size_t)node * V + n) * C];
+                    const float cv = (total >= 0 && cap_e != nullptr) ? cap_e[ck_e[j]] : capm[node * V + n];
                     ok = node != dst && !((gvis[(size_t)k * VW + (n >> 5)] >> (n & 31)) & 1u);
-                    if (ok) {
-                        const float cv = capm[node * V + n];
-                        ok = (cv != 0.f) && (!check_demand || demand <= cv);
-                        if (ok) sc = gscore[k] + yb[((size_t)node * V + n) * C];
-                    }
+                    ok = ok && (cv != 0.f) && (!check_demand || demand <= cv);
+                    if (ok) sc = gscore[k] + yv;
                 }
                 cs[j] = sc; ck[j] = ok; cidx[j] = idx;
                 any |= ok ? 1 : 0;
@@ -288,14 +411,7 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                 for (int j = 0; j < BEAM_CPL; ++j)
                     if (cidx[j] == c.idx) ck[j] = false;
                 const int k = c.idx / V, n = c.idx - k * V;
-                if (lane == 0) {
-                    L.beam_node[ngen * K + r] = n;
-                    L.beam_score[ngen * K + r] = c.score;
-                    npath[(size_t)r * V + len] = (unsigned short)n;
-                }
-                for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
-                for (int w = lane; w < VW; w += 64)
-                    nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+                commit(r, k, n, c.score);
                 nnb = r + 1;
             }
         } else {
@@ -331,15 +447,8 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                 c = beam_wave_best(c);
                 if (c.idx < 0) break;
                 const int k = c.idx / V, n = c.idx - k * V;
-                if (lane == 0) {
-                    L.cand_ok[c.idx] = 0;
-                    L.beam_node[ngen * K + r] = n;
-                    L.beam_score[ngen * K + r] = c.score;
-                    npath[(size_t)r * V + len] = (unsigned short)n;
-                }
-                for (int t = lane; t < len; t += 64) npath[(size_t)r * V + t] = gpath[(size_t)k * V + t];
-                for (int w = lane; w < VW; w += 64)
-                    nvis[(size_t)r * VW + w] = gvis[(size_t)k * VW + w] | ((w == (n >> 5)) ? (1u << (n & 31)) : 0u);
+                if (lane == 0) L.cand_ok[c.idx] = 0;
+                commit(r, k, n, c.score);
                 nnb = r + 1;
                 __syncthreads();
             }
@@ -363,7 +472,7 @@ __global__ __launch_bounds__(64) void k_beam_search(
     int cap_in_lds, int* __restrict__ paths, int* __restrict__ path_len, int* __restrict__ feasible,
     int* __restrict__ attempts, const int* __restrict__ spec_paths, const int* __restrict__ spec_len,
     const int* __restrict__ adj_ptr, const unsigned short* __restrict__ adj_col, const unsigned short* __restrict__ adj_row,
-    int nnzc) {
+    const float* __restrict__ y_e, int nnzc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
@@ -371,9 +480,11 @@ __global__ __launch_bounds__(64) void k_beam_search(
     if (algo == BEAM_ALGO_UNCONSTRAINED) {
         const int b = blockIdx.x / C, c = blockIdx.x - b * C;
         if (run_mask && !run_mask[b]) return;
-        beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
+        const int nnz_u = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
+        beam_fill_edge_caps(L, cap + (size_t)b * V * V, V);
+        if (nnz_u >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz_u);
         const long long* cm = comm + ((size_t)b * C + c) * 3;
-        const int len = beam_commodity(L, cap + (size_t)b * V * V, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0],
+        const int len = beam_commodity(L, cap + (size_t)b * V * V, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0],
                                        (int)cm[1], 0.f, 0);
         int* pb = paths + ((size_t)b * C + c) * PL;
         for (int t = lane; t < PL; t += 64) pb[t] = t < len ? (int)L.best_path[t] : -1;
@@ -407,6 +518,7 @@ __global__ __launch_bounds__(64) void k_beam_search(
             for (int t = lane; t < V * V; t += 64) wcap[t] = cap_b[t];
         }
         __syncthreads();
+        if (strict || count == 0) beam_fill_edge_caps(L, cap_b, V);      // the working capacities, per list entry
         ok = 1;
         for (int pos = 0; pos < C; ++pos) {
             const int c = perm ? perm[pos] : pos;
@@ -421,7 +533,7 @@ __global__ __launch_bounds__(64) void k_beam_search(
                 if (nnz >= 0) {         // edges without initial capacity are never used: only the listed ones can differ
                     for (int e = lane; e < nnz; e += 64) {
                         const int t = (int)rows_b[e] * V + (int)L.adj_col[e];
-                        const float c0 = cap_b[t], c1 = wcap[t];
+                        const float c0 = cap_b[t], c1 = L.cap_e[e];
                         diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
                     }
                 } else {
@@ -438,7 +550,8 @@ __global__ __launch_bounds__(64) void k_beam_search(
                 for (int t = lane; t < len; t += 64) L.best_path[t] = (unsigned short)spec_paths[((size_t)b * C + c) * PL + t];
                 __syncthreads();
             } else {
-                len = beam_commodity(L, strict ? wcap : cap_b, yb + c, V, C, K, s, d, demand, 1);
+                if (nnz >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz);
+                len = beam_commodity(L, strict ? wcap : cap_b, L.cap_e, yb + c, V, C, K, s, d, demand, 1);
             }
             if (len == 0) { ok = 0; break; }
             for (int t = lane; t < PL; t += 64) pb[(size_t)c * PL + t] = t < len ? (int)L.best_path[t] : -1;
@@ -447,6 +560,9 @@ __global__ __launch_bounds__(64) void k_beam_search(
                 for (int t = lane; t + 1 < len; t += 64) {
                     const int u = L.best_path[t], v = L.best_path[t + 1];
                     wcap[u * V + v] -= demand;      // a simple path uses each directed edge once
+                    if (L.cap_e != nullptr)
+                        for (int e = L.adj_ptr[u]; e < L.adj_ptr[u + 1]; ++e)
+                            if (L.adj_col[e] == v) L.cap_e[e] -= demand;
                 }
             }
             __syncthreads();
@@ -473,7 +589,7 @@ __global__ __launch_bounds__(64) void k_beam_spec(
     int B, int V, int C, int K, int algo, const float* __restrict__ y, const float* __restrict__ cap,
     const long long* __restrict__ comm, const unsigned char* __restrict__ run_mask, int cap_in_lds,
     int* __restrict__ spec_paths, int* __restrict__ spec_len, const int* __restrict__ adj_ptr,
-    const unsigned short* __restrict__ adj_col, int nnzc) {
+    const unsigned short* __restrict__ adj_col, const float* __restrict__ y_e, int nnzc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
@@ -482,13 +598,15 @@ __global__ __launch_bounds__(64) void k_beam_spec(
     if (run_mask && !run_mask[b]) return;
     if (algo == BEAM_ALGO_GREEDY) K = 1;
     const float* cap_b = cap + (size_t)b * V * V;
-    beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
+    const int nnz = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
+    beam_fill_edge_caps(L, cap_b, V);
+    if (nnz >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz);
     if (L.wcap) {
         for (int t = lane; t < V * V; t += 64) L.wcap[t] = cap_b[t];
         __syncthreads();
     }
     const long long* cm = comm + ((size_t)b * C + c) * 3;
-    const int len = beam_commodity(L, L.wcap ? L.wcap : cap_b, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
+    const int len = beam_commodity(L, L.wcap ? L.wcap : cap_b, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
                                    (float)cm[2], 1);
     for (int t = lane; t < len; t += 64) spec_paths[((size_t)b * C + c) * PL + t] = (int)L.best_path[t];
     if (lane == 0) spec_len[(size_t)b * C + c] = len;
