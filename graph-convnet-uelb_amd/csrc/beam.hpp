@@ -98,10 +98,11 @@ struct BeamLds {
 
 __host__ __device__ inline size_t beam_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// Adjacency lists pay when the dense candidate grid K x V does not fit the registers of a wavefront; they hold up to
-// 24 edges per node on average (denser graphs, or more than 2048 nodes, keep the dense scan).
+// Adjacency lists hold up to 24 edges per node on average (denser graphs, or more than 2048 nodes, keep the dense
+// scan).  They pay at every size: at 14 nodes the K x V grid fits the registers, but a step over the beams' out-edges
+// (K x 3 of them) is a third of the instructions of a step over the grid (0.25 -> 0.125 ms for 20 NSFNet graphs).
 __host__ __device__ inline int beam_adj_capacity(int V, int K) {
-    return (K * V > 64 * BEAM_CPL && K <= 64 && V <= 2048) ? 24 * V : 0;
+    return (K <= 64 && V <= 2048) ? 24 * V : 0;
 }
 __host__ __device__ inline size_t beam_lds_bytes(int V, int K, int cap_in_lds, int nnzc = 0) {
     const int VW = (V + 31) / 32;

@@ -169,11 +169,11 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
  *     first pass that searches every (graph, commodity) against the initial capacities in parallel; the ordered
  *     pass keeps such a result whenever the capacity updates so far leave that commodity's edge predicate
  *     (cap != 0 and demand <= cap) unchanged, and searches again otherwise: same paths as the sequential
- *     reference order, bit for bit.  With a smaller or null ws the first pass is skipped.  When the dense candidate
- *     grid K x V exceeds 256 entries the workspace also holds the graphs' adjacency lists (edges with non-zero
- *     capacity, up to 24 per node on average), built by a launch of their own: a step then examines the beams'
- *     out-edges instead of K x V entries, in the same order and with the same tie-break; graphs with more edges, or
- *     a smaller workspace, keep the dense scan.
+ *     reference order, bit for bit.  With a smaller or null ws the first pass is skipped.  The workspace also holds
+ *     the graphs' adjacency lists (edges with non-zero capacity, up to 24 per node on average) and the scores
+ *     gathered per list entry, built by two launches of their own: a step then examines the beams' out-edges
+ *     instead of K x V entries, in the same order and with the same tie-break; graphs with more edges, more than
+ *     2048 nodes, K > 64, or a smaller workspace keep the dense scan.
  * ---------------------------------------------------------------------------------------------- */
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K);
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
