@@ -97,7 +97,10 @@ def test_scores_from_logits_close_to_torch():
 @pytest.mark.parametrize("algo,strict,V,C,K,B", [("deterministic", True, 14, 20, 10, 40), ("standard", True, 14, 10, 10, 60),
                                                   ("unconstrained", False, 14, 20, 10, 20), ("greedy", True, 30, 6, 5, 16),
                                                   ("deterministic", False, 40, 5, 10, 20), ("deterministic", True, 100, 4, 10, 4),
-                                                  ("standard", True, 6, 4, 3, 33), ("deterministic", True, 5, 3, 50, 3)])
+                                                  ("standard", True, 6, 4, 3, 33), ("deterministic", True, 5, 3, 50, 3),
+                                                  # more beams than lanes: no adjacency lists (dense grid in LDS at
+                                                  # V = 5, in registers at V = 3)
+                                                  ("deterministic", True, 5, 3, 70, 3), ("deterministic", True, 3, 2, 80, 3)])
 def test_beam_matches_c_oracle_at_benchmark_sizes(algo, strict, V, C, K, B):
     """Random instances at and beyond the configs' sizes (V = 100 exercises the capacity matrix in
     global scratch instead of LDS; K = 50 > candidates exercises short queues)."""
