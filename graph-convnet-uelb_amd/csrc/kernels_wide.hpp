@@ -157,7 +157,7 @@ __device__ __forceinline__ void rot(f32x4 (&x)[WKB]) {
 // operands of half a group are requested before its first MFMA.
 template <int PIPE, int NS>
 __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW, int H, int NB, int nb, int rs, int q,
-                                             f32x4 (&o)[WNS]) {
+                                             f32x4 (&o)[WNS], unsigned long long* wait_acc = nullptr) {
     f32x4 a[NS], b[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { a[s] = f4zero(); b[s] = f4zero(); }
@@ -225,6 +225,13 @@ __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW
     } else {
         for (int s0 = 0; s0 < NB; s0 += 4) {
             load(wa, s0);
+#ifdef GCN_ACC_GEMM
+            {   // measurement builds: cycles spent waiting for the weight rows (and whatever was requested before them)
+                const unsigned long long t0 = clock64();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (wait_acc != nullptr) *wait_acc += clock64() - t0;
+            }
+#endif
             compute(wa, s0);
         }
     }
@@ -234,10 +241,10 @@ __device__ __forceinline__ void wide_gemm_ns(const float (*tile)[WLS], rsrc_t rW
 // ns (wavefront-uniform) = tiles in use, 1 .. WNS; o[s] for s >= ns is left untouched
 template <int PIPE>
 __device__ __forceinline__ void wide_gemm_n(const float (*tile)[WLS], int ns, rsrc_t rW, int H, int NB, int nb, int rs, int q,
-                                            f32x4 (&o)[WNS]) {
-    if (ns >= 3) wide_gemm_ns<PIPE, 3>(tile, rW, H, NB, nb, rs, q, o);
-    else if (ns == 2) wide_gemm_ns<PIPE, 2>(tile, rW, H, NB, nb, rs, q, o);
-    else wide_gemm_ns<PIPE, 1>(tile, rW, H, NB, nb, rs, q, o);
+                                            f32x4 (&o)[WNS], unsigned long long* wait_acc = nullptr) {
+    if (ns >= 3) wide_gemm_ns<PIPE, 3>(tile, rW, H, NB, nb, rs, q, o, wait_acc);
+    else if (ns == 2) wide_gemm_ns<PIPE, 2>(tile, rW, H, NB, nb, rs, q, o, wait_acc);
+    else wide_gemm_ns<PIPE, 1>(tile, rW, H, NB, nb, rs, q, o, wait_acc);
 }
 // zero columns 16 NB .. 16 ceil4(NB) - 1 of a 16 WNS-row LDS tile (never written afterwards)
 __device__ __forceinline__ void wide_zero_pad(float (*tile)[WLS], int NB, int t) {
@@ -400,7 +407,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
                             vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
                         }
                         f32x4 et2[WNS];
+#if defined(GCN_ACC_GEMM) && defined(GCN_PHASE_ACC) && GCN_PHASE_ACC == 1
+                        wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2, &pa_[7]);
+#else
                         wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2);
+#endif
                         if (kk == 0) GCN_STAMP_F(3);
                         ACCF(2);
                         f32x4 t1 = f4zero(), t2 = f4zero();

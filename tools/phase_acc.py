@@ -36,7 +36,7 @@ assert lib.gcn_phase_acc_read(buf) == 0
 t = np.array(buf[:], dtype=np.float64).reshape(1024, 4, 8)
 used = t.sum(axis=(1, 2)) > 0
 t = t[used]
-names = (["stage", "barrier", "product", "epilogue", "loop end", "barrier2", "tail", "-"] if which == "fwd" else
+names = (["stage", "barrier", "product", "epilogue", "loop end", "barrier2", "tail", "(weight wait inside product, -DGCN_ACC_GEMM)"] if which == "fwd" else
          ["node side", "barrier", "stage", "barrier", "product", "epilogue", "loop end", "barrier3"])
 tot = t.sum(axis=2)
 print(f"{int(used.sum())} workgroups; cycles per wavefront: mean {tot.mean():.0f}, min {tot.min():.0f}, max {tot.max():.0f}")
