@@ -170,7 +170,7 @@ def batch_sweep(name, shape, device, rank, batches=(20, 80, 320), steps=20):
 
 
 def beam_bench_large(device, B=2, V=200, C=100, K=10):
-    """Beam-search decode at the largest BASELINE configuration (200 nodes x 100 commodities, K = 10, strict,
+    """Beam-search decode at the largest benchmark configuration (BASELINE.json: 200 nodes x 100 commodities, K = 10, strict,
     deterministic): graphs/s, and the bytes of the score tensor y the search reads (4 V^2 bytes per commodity) over the
     decode time; the same decode by the C oracle on one host core next to it, paths compared bit for bit.  Scores favour
     each commodity's labelled path, as a trained model's would, so that graphs decode completely."""

@@ -198,7 +198,7 @@ def test_beam_tight_capacities_match_c_oracle(algo, V, C, K, B, seed):
 
 @pytest.mark.parametrize("algo,cap_lo,cap_hi", [("deterministic", 1000, 5000), ("standard", 1000, 5000), ("deterministic", 300, 1500)])
 def test_beam_at_200_nodes_100_commodities_matches_c_oracle(algo, cap_lo, cap_hi):
-    """The largest BASELINE configuration (V = 200, C = 100, K = 10, strict): 160 KB capacity matrices live in the
+    """The largest benchmark configuration (V = 200, C = 100, K = 10, strict): 160 KB capacity matrices live in the
     workspace instead of LDS, paths of up to 200 nodes, 100 sequentially dependent commodities per graph.  Scores
     favour each commodity's labelled path (as a trained model's would) with random decoys tied with the label edges,
     so that some graphs decode completely and others run into retries and the fallback; bit-exact against the

@@ -1,4 +1,4 @@
-"""GPU parity at the full sizes of the BASELINE configurations, against the oracle in float64 on the same seeded
+"""GPU parity at the full sizes of the benchmark configurations (BASELINE.json), against the oracle in float64 on the same seeded
 synthetic batch, every value held to the 1e-4 bound:
 
   * the three shipped configurations at B = 20 graphs and all L = 10 layers,
@@ -147,14 +147,14 @@ def test_full_config_forward_backward(name):
 
 
 def test_config4_100_nodes_50_commodities_h300_all_30_layers():
-    """BASELINE config 4 on its own workload: V = 100, C = 50, H = 300, L = 30 (all layers), one graph per GPU:
+    """Benchmark configuration 4 (BASELINE.json) on its own workload: V = 100, C = 50, H = 300, L = 30 (all layers), one graph per GPU:
     500,000 edge rows, a 600 MB edge tensor per layer in float32."""
     hip, _ = _check_config("synthetic_100n_50c_h300_l30", 1)
     _train_mode_properties(hip)
 
 
 def test_config5_200_nodes_100_commodities_all_layers():
-    """BASELINE config 5 on its own workload: V = 200, C = 100, H = 64, L = 10, one graph per GPU: 4,000,000 edge
+    """Benchmark configuration 5 (BASELINE.json) on its own workload: V = 200, C = 100, H = 64, L = 10, one graph per GPU: 4,000,000 edge
     rows, a 1 GB edge tensor per layer."""
     hip, _ = _check_config("synthetic_200n_100c", 1)
     _train_mode_properties(hip)
