@@ -268,9 +268,54 @@ __device__ __forceinline__ int lds_opaque_zero() {
     return z;
 }
 
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* __restrict__ p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Buffer addressing: a 128-bit descriptor (base, byte count) built from workgroup-uniform values plus a
+// 32-bit per-lane byte offset.  The hardware range-checks the offset: loads beyond the byte count return
+// 0 and stores are dropped, so ragged tiles need neither clamped addresses nor predicated (branched-around)
+// memory instructions, and every memory instruction in a loop body is issued unconditionally.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;        // an offset beyond any descriptor used here (all are < 2 GiB)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float bld1(rsrc_t r, uint32_t voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
 // Channel constants: nvec vectors of H floats copied into LDS rows of HP = 16*MT floats (zero padded).
 __device__ __forceinline__ void clds_fill(float* __restrict__ dst, const float* __restrict__ src, int H, int HP) {
     for (int t = threadIdx.x; t < HP; t += blockDim.x) dst[t] = (src != nullptr && t < H) ? src[t] : 0.f;
+}
+// N such vectors at once.  One clds_fill after another is a chain of N memory round trips in the prologue of every
+// workgroup (load, wait, LDS store, next vector): here all loads are requested before the first is stored.  Range-checked
+// buffer loads make a null source or an element beyond H read as 0 without a branch.  ITERS = ceil(HP / blockDim.x).
+template <int N, int ITERS = 1>
+__device__ __forceinline__ void clds_fill_batch(float* const (&dst)[N], const float* const (&src)[N], int H, int HP) {
+    float v[N][ITERS];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const rsrc_t r = make_rsrc(src[k], src[k] != nullptr ? (uint32_t)H * 4u : 0u);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) v[k][it] = bld1(r, (uint32_t)(threadIdx.x + it * blockDim.x) * 4u);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int t = threadIdx.x + it * blockDim.x;
+            if (t < HP) dst[k][t] = v[k][it];
+        }
 }
 __device__ __forceinline__ f32x4 clds_get(const float* __restrict__ row, int m, int q) {
     return *reinterpret_cast<const f32x4*>(row + 16 * m + 4 * q);

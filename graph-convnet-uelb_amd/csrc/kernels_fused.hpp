@@ -29,11 +29,10 @@ enum { CL_PMEAN = 0, CL_PRSTD = 1, CL_PGAMMA = 2, CL_PBETA = 3, CL_WE = 4, CL_RO
 template <int MT>
 __device__ __forceinline__ void edge_src_fill_consts(float (*cl)[16 * MT], const EdgeSrc& S, int H) {
     constexpr int HP = 16 * MT;
-    clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP);
-    clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
-    clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP);
-    clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
-    clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
+    float* const dst[5] = {cl[CL_PMEAN], cl[CL_PRSTD], cl[CL_PGAMMA], cl[CL_PBETA], cl[CL_WE]};
+    const float* const src[5] = {S.mode == 1 ? S.pmean : nullptr, S.mode == 1 ? S.prstd : nullptr, S.mode == 1 ? S.pgamma : nullptr,
+                                 S.mode == 1 ? S.pbeta : nullptr, S.mode == 2 ? S.we : nullptr};
+    clds_fill_batch<5>(dst, src, H, HP);
 }
 
 // Returns the tile of edge row `erow` (lane's row; !valid -> zeros).  If XH / DMR are non-null (mode 1

@@ -22,31 +22,6 @@ struct StripGeom {
     static constexpr int G = 4 * MT;           // float4 column groups per row
 };
 
-__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* __restrict__ p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-
-// Buffer addressing: a 128-bit descriptor (base, byte count) built from workgroup-uniform values plus a
-// 32-bit per-lane byte offset.  The hardware range-checks the offset: loads beyond the byte count return
-// 0 and stores are dropped, so ragged tiles need neither clamped addresses nor predicated (branched-around)
-// memory instructions, and every memory instruction in a loop body is issued unconditionally.
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t kOob = 0x80000000u;        // an offset beyond any descriptor used here (all are < 2 GiB)
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-    const uint64_t p = (uint64_t)base;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-__device__ __forceinline__ f32x4 bld4(rsrc_t r, uint32_t voff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
-}
-__device__ __forceinline__ float bld1(rsrc_t r, uint32_t voff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-}
-__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, const f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
-}
-
 // out[16w + 4q + r] for row rs = sum_k tile[rs][k] * Wrow[16w + ..][k]; two accumulation chains hide the
 // 40-cycle dependent latency of v_mfma_f32_16x16x4_f32.
 template <int MT>
@@ -380,14 +355,14 @@ __global__ __launch_bounds__(64 * MT, 3) void k_edge_bwd3(EdgeBwdArgs a) {
     const bool do_next = a.next.tmp != nullptr;
     const bool mean_agg = a.mean_agg != 0;
     const float* __restrict__ ntmp = do_next ? a.next.tmp : a.e_tmp;     // always a readable edge tensor
-    clds_fill(ce[0], a.stats, H, HP); clds_fill(ce[1], a.stats + H, H, HP);
-    clds_fill(ce[2], a.gamma_e, H, HP); clds_fill(ce[3], a.beta_e, H, HP);
-    clds_fill(ce[4], a.bstats_e, H, HP); clds_fill(ce[5], a.bstats_e + H, H, HP);
-    clds_fill(cx[0], a.stats + 2 * H, H, HP); clds_fill(cx[1], a.stats + 3 * H, H, HP);
-    clds_fill(cx[2], a.gamma_x, H, HP); clds_fill(cx[3], a.beta_x, H, HP);
-    clds_fill(cx[4], a.bstats_x, H, HP); clds_fill(cx[5], a.bstats_x + H, H, HP);
-    clds_fill(ncl[0], do_next ? a.next.mean : nullptr, H, HP); clds_fill(ncl[1], do_next ? a.next.rstd : nullptr, H, HP);
-    clds_fill(ncl[2], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(ncl[3], do_next ? a.next.beta : nullptr, H, HP);
+    {
+        float* const dst[16] = {ce[0], ce[1], ce[2], ce[3], ce[4], ce[5], cx[0], cx[1], cx[2], cx[3], cx[4], cx[5], ncl[0], ncl[1], ncl[2], ncl[3]};
+        const float* const src[16] = {a.stats, a.stats + H, a.gamma_e, a.beta_e, a.bstats_e, a.bstats_e + H,
+                                      a.stats + 2 * H, a.stats + 3 * H, a.gamma_x, a.beta_x, a.bstats_x, a.bstats_x + H,
+                                      do_next ? a.next.mean : nullptr, do_next ? a.next.rstd : nullptr,
+                                      do_next ? a.next.gamma : nullptr, do_next ? a.next.beta : nullptr};
+        clds_fill_batch<16>(dst, src, H, HP);
+    }
     const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
     const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
     const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);

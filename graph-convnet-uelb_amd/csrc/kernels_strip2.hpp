@@ -302,14 +302,14 @@ __global__ __launch_bounds__(32 * MT, 2) void k_edge_bwd4(EdgeBwdArgs a) {
     const bool do_next = a.next.tmp != nullptr;
     const bool mean_agg = a.mean_agg != 0;
     const float* __restrict__ ntmp = do_next ? a.next.tmp : a.e_tmp;     // always a readable edge tensor
-    clds_fill(ce[0], a.stats, H, HP); clds_fill(ce[1], a.stats + H, H, HP);
-    clds_fill(ce[2], a.gamma_e, H, HP); clds_fill(ce[3], a.beta_e, H, HP);
-    clds_fill(ce[4], a.bstats_e, H, HP); clds_fill(ce[5], a.bstats_e + H, H, HP);
-    clds_fill(cx[0], a.stats + 2 * H, H, HP); clds_fill(cx[1], a.stats + 3 * H, H, HP);
-    clds_fill(cx[2], a.gamma_x, H, HP); clds_fill(cx[3], a.beta_x, H, HP);
-    clds_fill(cx[4], a.bstats_x, H, HP); clds_fill(cx[5], a.bstats_x + H, H, HP);
-    clds_fill(ncl[0], do_next ? a.next.mean : nullptr, H, HP); clds_fill(ncl[1], do_next ? a.next.rstd : nullptr, H, HP);
-    clds_fill(ncl[2], do_next ? a.next.gamma : nullptr, H, HP); clds_fill(ncl[3], do_next ? a.next.beta : nullptr, H, HP);
+    {
+        float* const dst[16] = {ce[0], ce[1], ce[2], ce[3], ce[4], ce[5], cx[0], cx[1], cx[2], cx[3], cx[4], cx[5], ncl[0], ncl[1], ncl[2], ncl[3]};
+        const float* const src[16] = {a.stats, a.stats + H, a.gamma_e, a.beta_e, a.bstats_e, a.bstats_e + H,
+                                      a.stats + 2 * H, a.stats + 3 * H, a.gamma_x, a.beta_x, a.bstats_x, a.bstats_x + H,
+                                      do_next ? a.next.mean : nullptr, do_next ? a.next.rstd : nullptr,
+                                      do_next ? a.next.gamma : nullptr, do_next ? a.next.beta : nullptr};
+        clds_fill_batch<16>(dst, src, H, HP);
+    }
     const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
     const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
     const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
