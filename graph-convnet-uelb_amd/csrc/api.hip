@@ -1271,6 +1271,13 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             jobs.n = nj;
             MidMap map = {};
             int nb = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+            if (const char* e = tune_env("GCN_TUNE_MIDPROBE")) {     // timing probe: segments of the launch dropped (results are then wrong)
+                const int mk = atoi(e);
+                if (mk & 1) nb = 0;
+                if (mk & 2) pr.nslices[0] = 0;
+                if (mk & 4) pr.nslices[1] = pr.nslices[2] = pr.nslices[3] = 0;
+                if (mk & 8) { nj = 0; jobs.n = 0; }
+            }
             map.seg[1] = nb;
             for (int k = 0; k < 4; ++k) { nb += pr.nslices[k]; map.seg[2 + k] = nb; }
             for (int k = 0; k < 4; ++k) { if (k < nj) nb += red_blocks(jobs.job[k]); map.seg[6 + k] = nb; }
