@@ -127,12 +127,14 @@ Dims make_dims(int B, int V, int C, int H) {
     d.grid_f = d.grid_b = 512;                              // two workgroups per CU
     d.MT = (H + 15) / 16;
     // Edge kernels with two column blocks per wavefront and the edge weight-gradient product inside the backward kernel
-    // (kernels_strip2.hpp): from about a million edge rows on, where the det tensor (written by the edge kernel, read
+    // (kernels_strip2.hpp): from about 300,000 edge rows on, where the det tensor (written by the edge kernel, read
     // back with the layer input by a product kernel) is HBM traffic worth removing: 200 nodes x 100 commodities runs 5 %
-    // faster with them and moves two edge tensors less per layer.  Below that everything sits in the caches and the
-    // kernels with one wavefront per column block are faster (same-box A/B: 3 % at nsfnet_10, 6 % at default2, 11 % at
-    // nsfnet_20): a wavefront's step is a chain of dependent phases, and twice the work per wavefront doubles it.
-    d.two_blocks = (d.MT == 2 || d.MT == 4) && d.Re >= 1000000;
+    // faster with them and moves two edge tensors less per layer.  Below that the launch floor and the first steps of
+    // every workgroup dominate and the kernels with one wavefront per column block are faster (same-box A/B of whole
+    // steps: nsfnet_10 at 20 / 80 / 120 graphs 3 / 2 / 1 % slower with two blocks, at 160 / 200 / 320 / 640 graphs
+    // 2 / 8 / 8 / 10 % faster; default2 at 20 graphs 6 % slower, at 40 / 60 / 80 graphs 9 / 9 / 4 % faster; nsfnet_20
+    // at 20 graphs 11 % slower): the crossover lies between 235,000 and 314,000 rows.
+    d.two_blocks = (d.MT == 2 || d.MT == 4) && d.Re >= 300000;
     if (const char* e = tune_env("GCN_TUNE_TWOBLOCKS")) d.two_blocks = (d.MT == 2 || d.MT == 4) && atoi(e) != 0;
     d.fuse_wg = d.two_blocks;
     if (const char* e = tune_env("GCN_TUNE_FUSE")) d.fuse_wg = d.two_blocks && atoi(e) != 0;
