@@ -161,7 +161,22 @@ Dims make_dims(int B, int V, int C, int H) {
                 }
             }
         d.grid_f = busiest((long long)d.Rn, grids[1], d.njt) < busiest((long long)d.Rn, grids[0], d.njt) ? grids[1] : grids[0];
-        if (d.two_blocks) d.grid_f = d.grid_b = 1024;           // workgroups of two wavefronts, four per CU (measured: 1024 and 2048 alike, 1536 5 % slower)
+        if (d.two_blocks) {
+            // Workgroups of two wavefronts, four per CU (measured: 1024 and 2048 alike, 1536 5 % slower).  The chunk
+            // length is the one that leaves the busiest CU the fewest steps at that grid, every chunk count n weighted
+            // by the traffic of its column partial sums (2 n node tensors written and read against 5 V node tensors
+            // of edge traffic).  Measured against the choice above: 200 nodes x 100 commodities 25 rows instead of
+            // 100 (867 -> 1015 workgroups with equal ranges), 113.4 -> 108.7 ms per step; nsfnet_10 at 320 graphs 7
+            // rows instead of 14, 6.17 -> 5.80 ms.
+            d.grid_f = d.grid_b = 1024;
+            double bestc = -1.0;
+            for (int it = 1; it <= V; ++it) {
+                if (balanced(it) != it) continue;
+                const int n = (V + it - 1) / it;
+                const double c = (double)busiest((long long)B * n * d.njt * C, d.grid_b, it) * (1.0 + 0.8 * n / V);
+                if (bestc < 0 || c < bestc) { bestc = c; d.IT = it; }
+            }
+        }
     } else if (d.IT > 3) {
         d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
     }
