@@ -196,8 +196,18 @@ int check_dims(int B, int V, int C, int H) {
     return 0;
 }
 
+constexpr int kMaxHeadBlocks = 2048;   // as many rows as the BatchNorm-backward partial buffers hold
 inline int wave_blocks(size_t units, int cap = 512) {
     return (int)std::max<size_t>(1, std::min<size_t>((units + GCN_WAVES_PER_BLOCK - 1) / GCN_WAVES_PER_BLOCK, (size_t)cap));
+}
+// Workgroups of the head kernels (one 16-row tile per step, grid-stride).  Forward strip kernel: four per CU (its step
+// ends in a serial stretch of one wavefront, softmax and loss of 16 rows, which more resident workgroups cover:
+// 4.49 -> 3.15 ms at 200 nodes x 100 commodities, 194 -> 140 us for 320 NSFNet graphs, 18.0 -> 16.9 us for 20); the
+// backward kernel (165 registers) and the wide kernels stay at two per CU (no gain from more).
+inline int head_blocks(size_t tiles, bool forward, int H) {
+    int cap = (forward && H <= 64) ? 1024 : 512;
+    if (const char* e = tune_env(forward ? "GCN_TUNE_GRID_H" : "GCN_TUNE_GRID_HB")) cap = std::max(1, std::min(atoi(e), kMaxHeadBlocks));
+    return wave_blocks(tiles, cap);
 }
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
@@ -678,7 +688,7 @@ struct ModelFwdWs {
 ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     ModelFwdWs w;
     w.lw = carve_fwd_ws(p.d, b);
-    w.head_blk = wave_blocks((p.d.Re + 15) / 16);
+    w.head_blk = head_blocks((p.d.Re + 15) / 16, true, p.d.H);
     w.loss_partial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * 2);
     w.count_rep = (int*)b.raw((size_t)kCountReps * 2 * p.d.B * p.d.C * sizeof(int));
     const bool deep_wide = p.d.MT > 4 && p.NHID > 1;
@@ -713,7 +723,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     // before layer L-1 starts); deeper MLPs get NHID contiguous slabs of their own
     w.dpre_stash = p.NHID > 1 ? b.f((size_t)p.NHID * eh) : nullptr;
     w.h_stash = p.NHID > 1 ? b.f((size_t)(p.NHID - 1) * eh) : nullptr;
-    w.head_blk = wave_blocks((p.d.Re + 15) / 16);
+    w.head_blk = head_blocks((p.d.Re + 15) / 16, false, p.d.H);
     w.wpartial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * (size_t)((p.voc * p.d.H + p.voc + 3) & ~3));
     w.S_h = tn_slices(p.d.Re, p.d.H);
     w.tn_h = b.f((size_t)w.S_h * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));
