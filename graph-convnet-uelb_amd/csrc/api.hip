@@ -1431,11 +1431,22 @@ static size_t beam_ws_base_bytes(int B, int V, int C) {
     return align_up((size_t)B * V * V * sizeof(float)) + align_up((size_t)B * C * sizeof(int)) +
            align_up((size_t)B * C * PL * sizeof(int));
 }
+// ... then the state of the ordered walk between rounds: [B][4] ints and the working capacities per list entry [B][nnzc]
+static size_t beam_ws_lists_bytes(int B, int V, int C, size_t nnzc) {
+    return align_up((size_t)B * (V + 1) * sizeof(int)) + 2 * align_up((size_t)B * nnzc * sizeof(unsigned short)) +
+           align_up((size_t)B * C * nnzc * sizeof(float));
+}
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K) {
     if (B <= 0 || V <= 0 || C <= 0) return 0;
     const size_t nnzc = K > 0 ? (size_t)beam_adj_capacity(V, K) : 0;
-    return beam_ws_base_bytes(B, V, C) + (nnzc ? align_up((size_t)B * (V + 1) * sizeof(int)) + 2 * align_up((size_t)B * nnzc * sizeof(unsigned short)) +
-                                                 align_up((size_t)B * C * nnzc * sizeof(float)) : 0);
+    return beam_ws_base_bytes(B, V, C) + (nnzc ? beam_ws_lists_bytes(B, V, C, nnzc) + align_up((size_t)B * 4 * sizeof(int)) +
+                                                 align_up((size_t)B * nnzc * sizeof(float)) : 0);
+}
+// Rounds of the ordered walk (k_beam_search): worth their launches when a search is long (large graphs: the working
+// capacities do not fit LDS) and there are many commodities to speculate on.  One round per four commodities, at most 32.
+static int beam_rounds(int V, int C, bool strict, int cap_in_lds, int nnzc, bool have_spec) {
+    if (!strict || cap_in_lds || !nnzc || !have_spec || C < 16) return 0;
+    return std::min(32, C / 4);
 }
 
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
@@ -1496,13 +1507,38 @@ int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, 
         }
         GCN_PROF_PRE("k_beam_spec");
         k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths, spec_len,
-                                             adj_ptr, adj_col, y_e, nnzc);
+                                             adj_ptr, adj_col, y_e, nnzc, nullptr, nullptr, nullptr, perms, n_perms, perm_start);
         GCN_CHECK_LAUNCH("k_beam_spec");
+        const int rounds = beam_rounds(V, C, strict, cap_in_lds, nnzc, true);
+        if (rounds > 0) {
+            // the ordered walk in rounds: walk until a commodity's predicate differs from the snapshot, search all the
+            // remaining commodities against the capacities reached, walk on (see k_beam_search); the last launch
+            // finishes whatever is left one commodity after the other
+            int* state = (int*)((char*)y_e + align_up((size_t)B * C * nnzc * sizeof(float)));
+            float* work_e = (float*)((char*)state + align_up((size_t)B * 4 * sizeof(int)));
+            for (int r = 0; r <= rounds; ++r) {
+                const int mode = r == 0 ? 1 : (r < rounds ? 2 : 3);
+                if (r > 0) {
+                    GCN_PROF_PRE("k_beam_spec");
+                    k_beam_spec<<<B * C, 64, slds, st>>>(B, V, C, K, algorithm, y, cap, comm, run_mask, spec_cap_lds, spec_paths,
+                                                         spec_len, adj_ptr, adj_col, y_e, nnzc, state, work_e, (const float*)ws,
+                                                         perms, n_perms, perm_start);
+                    GCN_CHECK_LAUNCH("k_beam_spec");
+                }
+                GCN_PROF_PRE("k_beam_search");
+                k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, 1, max_iter, y, cap, comm, perms, n_perms, perm_start,
+                                                     run_mask, (float*)ws, cap_in_lds, paths, path_len, feasible, attempts,
+                                                     spec_paths, spec_len, adj_ptr, adj_col, adj_row, y_e, nnzc, mode, state, work_e);
+                GCN_CHECK_LAUNCH("k_beam_search");
+            }
+            return 0;
+        }
     }
     GCN_PROF_PRE("k_beam_search");
     k_beam_search<<<jobs, 64, lds, st>>>(B, V, C, K, algorithm, strict ? 1 : 0, max_iter, y, cap, comm, perms,
                                                           n_perms, perm_start, run_mask, (float*)ws, cap_in_lds, paths, path_len,
-                                                          feasible, attempts, spec_paths, spec_len, adj_ptr, adj_col, adj_row, y_e, nnzc);
+                                                          feasible, attempts, spec_paths, spec_len, adj_ptr, adj_col, adj_row, y_e, nnzc,
+                                                          0, nullptr, nullptr);
     GCN_CHECK_LAUNCH("k_beam_search");
     return 0;
 }

@@ -466,6 +466,17 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
 // run_mask (nullable): graphs with run_mask[b] == 0 are skipped (outputs untouched).
 // capws: [B][V][V] floats of global scratch, used as the working capacity in strict mode when the
 // matrix does not fit LDS.  paths: [B][C][PL] int32 padded with -1, PL = max(V, 10).
+//
+// Rounds (round_mode != 0; strict mode with adjacency lists and the working capacities in global memory): the ordered
+// walk is split over several launches with a speculative pass between them.  A launch keeps first-pass results while
+// the commodity's edge predicate is the same on the working capacities as on the snapshot the first pass searched
+// against; at the first commodity for which it differs, modes 1 and 2 save the graph's state (position, attempt,
+// working capacities per list entry in work_e; the dense matrix lives in capws) and return, and the next speculative
+// pass searches every remaining commodity against exactly those capacities, all in parallel - its result for the
+// commodity that stopped the walk is therefore final, and so is every following one until the updates change a
+// predicate again.  Mode 3 (last launch) searches such commodities itself, one after the other.  Same results as the
+// single ordered walk.  state: [B][4] = {position, attempt, finished, attempts counted}.
+//   round_mode 0: single launch (no state); 1: first round (snapshot = initial capacities); 2: later round; 3: last.
 __global__ __launch_bounds__(64) void k_beam_search(
     int B, int V, int C, int K, int algo, int strict, int max_iter, const float* __restrict__ y,
     const float* __restrict__ cap, const long long* __restrict__ comm, const int* __restrict__ perms, int n_perms,
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(64) void k_beam_search(
     int cap_in_lds, int* __restrict__ paths, int* __restrict__ path_len, int* __restrict__ feasible,
     int* __restrict__ attempts, const int* __restrict__ spec_paths, const int* __restrict__ spec_len,
     const int* __restrict__ adj_ptr, const unsigned short* __restrict__ adj_col, const unsigned short* __restrict__ adj_row,
-    const float* __restrict__ y_e, int nnzc) {
+    const float* __restrict__ y_e, int nnzc, int round_mode, int* __restrict__ state, float* __restrict__ work_e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
@@ -497,44 +508,63 @@ __global__ __launch_bounds__(64) void k_beam_search(
     }
     const int b = blockIdx.x;
     if (run_mask && !run_mask[b]) return;
+    int* stb = state ? state + (size_t)b * 4 : nullptr;
+    if (round_mode >= 2 && stb[2]) return;                 // finished in an earlier round
     if (algo == BEAM_ALGO_GREEDY) K = 1;
     const float* cap_b = cap + (size_t)b * V * V;
     const int nnz = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
     const unsigned short* rows_b = adj_row ? adj_row + (size_t)b * nnzc : nullptr;
     float* wcap = strict ? (L.wcap ? L.wcap : capws + (size_t)b * V * V) : nullptr;
+    float* we_b = work_e ? work_e + (size_t)b * nnzc : nullptr;
     const float* yb = y + (size_t)b * V * V * C;
     const long long* cm = comm + (size_t)b * C * 3;
     int* pb = paths + (size_t)b * C * PL;
     int* plb = path_len + (size_t)b * C;
-    int used = 0, ok = 0;
-    for (int count = 0; count < max_iter; ++count) {
+    // a graph without adjacency lists (denser than they hold) is walked to the end in the first round
+    const bool may_stop = (round_mode == 1 || round_mode == 2) && nnz >= 0;
+    const int count0 = round_mode >= 2 ? stb[1] : 0;
+    const int pos0 = round_mode >= 2 ? stb[0] : 0;
+    int used = round_mode >= 2 ? stb[3] : 0, ok = 0;
+    for (int count = count0; count < max_iter; ++count) {
         const int* perm = nullptr;
         if (algo != BEAM_ALGO_DETERMINISTIC) {
             const int pi = perm_start[b] + count;
             if (pi >= n_perms) break;          // host supplies max_iter permutations per graph; defensive
             perm = perms + (size_t)pi * C;
         }
-        ++used;
-        if (strict) {
-            for (int t = lane; t < V * V; t += 64) wcap[t] = cap_b[t];
+        // resumed: this attempt was begun by an earlier launch (its capacities are in capws / work_e, and the first
+        // pass before this launch searched against them)
+        const bool resumed = round_mode >= 2 && count == count0;
+        if (!resumed) {
+            ++used;
+            if (strict) {
+                for (int t = lane; t < V * V; t += 64) wcap[t] = cap_b[t];
+            }
         }
         __syncthreads();
-        if (strict || count == 0) beam_fill_edge_caps(L, cap_b, V);      // the working capacities, per list entry
+        if (resumed) {
+            for (int e = lane; e < nnz; e += 64) L.cap_e[e] = we_b[e];
+            __syncthreads();
+        } else if (strict || count == 0) {
+            beam_fill_edge_caps(L, cap_b, V);      // the working capacities, per list entry
+        }
+        // first-pass results are usable while they were searched against this attempt's snapshot: the initial
+        // capacities (modes 0 and 1, any attempt) or the saved capacities of the resumed attempt
+        const bool spec_ok = spec_len != nullptr && (round_mode <= 1 || resumed);
         ok = 1;
-        for (int pos = 0; pos < C; ++pos) {
+        for (int pos = resumed ? pos0 : 0; pos < C; ++pos) {
             const int c = perm ? perm[pos] : pos;
             const int s = (int)cm[c * 3], d = (int)cm[c * 3 + 1];
             const float demand = (float)cm[c * 3 + 2];
             // A commodity's search depends on the capacities only through the edge predicate
             // (cap != 0 and demand <= cap).  If that predicate is the same on the working capacities as on the
-            // initial ones, the search k_beam_spec ran against the initial capacities is this search exactly.
-            bool reuse = spec_len != nullptr;
+            // snapshot, the search the first pass ran against the snapshot is this search exactly.
+            bool reuse = spec_ok;
             if (reuse && strict) {
                 int diff = 0;
                 if (nnz >= 0) {         // edges without initial capacity are never used: only the listed ones can differ
                     for (int e = lane; e < nnz; e += 64) {
-                        const int t = (int)rows_b[e] * V + (int)L.adj_col[e];
-                        const float c0 = cap_b[t], c1 = L.cap_e[e];
+                        const float c0 = resumed ? we_b[e] : cap_b[(int)rows_b[e] * V + (int)L.adj_col[e]], c1 = L.cap_e[e];
                         diff |= ((c0 != 0.f) && (demand <= c0)) != ((c1 != 0.f) && (demand <= c1)) ? 1 : 0;
                     }
                 } else {
@@ -544,6 +574,12 @@ __global__ __launch_bounds__(64) void k_beam_search(
                     }
                 }
                 reuse = !__any(diff);
+            }
+            if (!reuse && may_stop) {
+                // save the attempt and leave this commodity (and the rest) to the next first pass
+                for (int e = lane; e < nnz; e += 64) we_b[e] = L.cap_e[e];
+                if (lane == 0) { stb[0] = pos; stb[1] = count; stb[2] = 0; stb[3] = used; }
+                return;
             }
             int len;
             if (reuse) {
@@ -570,6 +606,16 @@ __global__ __launch_bounds__(64) void k_beam_search(
         }
         if (ok) break;
         if (algo == BEAM_ALGO_DETERMINISTIC) { used = max_iter; break; }   // identical retries, identical result
+        if (round_mode == 2 && count + 1 < max_iter && perm_start[b] + count + 1 < n_perms) {
+            // The next attempt starts from the initial capacities, which the first-pass results at hand were not
+            // searched against: set the attempt up and leave it to the next round.
+            for (int t = lane; t < V * V; t += 64) wcap[t] = cap_b[t];
+            __syncthreads();
+            beam_fill_edge_caps(L, cap_b, V);
+            for (int e = lane; e < nnz; e += 64) we_b[e] = L.cap_e[e];
+            if (lane == 0) { stb[0] = 0; stb[1] = count + 1; stb[2] = 0; stb[3] = used + 1; }
+            return;
+        }
     }
     if (!ok) {
         for (int t = lane; t < C * PL; t += 64) {
@@ -578,41 +624,67 @@ __global__ __launch_bounds__(64) void k_beam_search(
         }
         for (int c = lane; c < C; c += 64) plb[c] = 10;
     }
-    if (lane == 0) { feasible[b] = ok; attempts[b] = used; }
+    if (lane == 0) {
+        feasible[b] = ok; attempts[b] = used;
+        if (stb) stb[2] = 1;
+    }
 }
 
-// y from the network output, BeamSearchAlgorithm.__init__ (:14-21).
-// five_d != 0: logits [rows][2] -> y[row] = log_softmax(.)[1]; thread per row.
 // Every (graph, commodity) searched against the graph's initial capacities, all in parallel: one wavefront
 // per job.  k_beam_search then walks the commodities in order and keeps a result whenever the capacity
 // updates so far leave the commodity's edge predicate unchanged (the common case), re-searching otherwise.
+// state / work_e / capws (rounds after the first, see k_beam_search): job (b, p) is position p of graph b's current
+// attempt; positions already walked and finished graphs return at once, the others search against the saved working
+// capacities.  With state == nullptr job (b, c) searches commodity c against the initial capacities.
 __global__ __launch_bounds__(64) void k_beam_spec(
     int B, int V, int C, int K, int algo, const float* __restrict__ y, const float* __restrict__ cap,
     const long long* __restrict__ comm, const unsigned char* __restrict__ run_mask, int cap_in_lds,
     int* __restrict__ spec_paths, int* __restrict__ spec_len, const int* __restrict__ adj_ptr,
-    const unsigned short* __restrict__ adj_col, const float* __restrict__ y_e, int nnzc) {
+    const unsigned short* __restrict__ adj_col, const float* __restrict__ y_e, int nnzc,
+    const int* __restrict__ state, const float* __restrict__ work_e, const float* __restrict__ capws,
+    const int* __restrict__ perms, int n_perms, const int* __restrict__ perm_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int PL = V > 10 ? V : 10;
-    BeamLds L = beam_carve(smem, V, K, cap_in_lds, nnzc);
-    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    const int b = blockIdx.x / C;
+    int c = blockIdx.x - b * C;
     if (run_mask && !run_mask[b]) return;
+    if (state != nullptr) {
+        const int* stb = state + (size_t)b * 4;
+        if (stb[2] || c < stb[0]) return;
+        if (algo != BEAM_ALGO_DETERMINISTIC) {
+            const int pi = perm_start[b] + stb[1];
+            if (pi >= n_perms) return;
+            c = perms[(size_t)pi * C + c];
+        }
+    }
+    BeamLds L = beam_carve(smem, V, K, cap_in_lds, nnzc);
     if (algo == BEAM_ALGO_GREEDY) K = 1;
     const float* cap_b = cap + (size_t)b * V * V;
     const int nnz = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
-    beam_fill_edge_caps(L, cap_b, V);
+    const float* dense = cap_b;
+    if (state != nullptr) {
+        if (nnz < 0) return;                   // such a graph finished in the first round
+        for (int e = lane; e < nnz; e += 64) L.cap_e[e] = work_e[(size_t)b * nnzc + e];
+        __syncthreads();
+        dense = capws + (size_t)b * V * V;
+    } else {
+        beam_fill_edge_caps(L, cap_b, V);
+    }
     if (nnz >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz);
     if (L.wcap) {
-        for (int t = lane; t < V * V; t += 64) L.wcap[t] = cap_b[t];
+        for (int t = lane; t < V * V; t += 64) L.wcap[t] = dense[t];
         __syncthreads();
     }
     const long long* cm = comm + ((size_t)b * C + c) * 3;
-    const int len = beam_commodity(L, L.wcap ? L.wcap : cap_b, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
+    const int len = beam_commodity(L, L.wcap ? L.wcap : dense, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
                                    (float)cm[2], 1);
     for (int t = lane; t < len; t += 64) spec_paths[((size_t)b * C + c) * PL + t] = (int)L.best_path[t];
     if (lane == 0) spec_len[(size_t)b * C + c] = len;
 }
 
+// y from the network output, BeamSearchAlgorithm.__init__ (:14-21).
+// five_d != 0: logits [rows][2] -> y[row] = log_softmax(.)[1]; thread per row.
 __global__ void k_beam_scores_2class(size_t rows, const float* __restrict__ logits, float* __restrict__ y) {
     for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (size_t)gridDim.x * blockDim.x) {
         const float l0 = logits[r * 2], l1 = logits[r * 2 + 1];

@@ -229,3 +229,36 @@ def test_beam_at_200_nodes_100_commodities_matches_c_oracle(algo, cap_lo, cap_hi
         assert int(a.attempts.sum()) == used
     if cap_lo == 1000:
         assert rf.max() == 1 and rl.max() > 10          # at least one graph decoded completely, with long paths
+
+
+@pytest.mark.parametrize("algo,V,C,K,B,cap_hi,seed", [("standard", 120, 24, 6, 3, 700, 11), ("greedy", 120, 32, 4, 3, 700, 12),
+                                                      ("deterministic", 96, 40, 8, 3, 1200, 13), ("standard", 128, 17, 10, 2, 400, 14)])
+def test_beam_ordered_walk_in_rounds_matches_c_oracle(algo, V, C, K, B, cap_hi, seed):
+    """Graphs whose capacity matrix does not fit LDS, 16 commodities or more, strict mode: the ordered walk runs in
+    rounds (walk until a commodity's edge predicate differs from the snapshot, search all remaining commodities in
+    parallel against the capacities reached, walk on).  Capacities of the order of the demands make predicates change
+    often, attempts fail and restart from the initial capacities in the middle of the rounds, and some graphs end in
+    the fallback; paths, lengths, feasibility and the number of attempts must equal the sequential C oracle's."""
+    from src.common.synthetic import make_batch
+    dev = _dev()
+    rng = np.random.default_rng(2000 + seed)
+    b = make_batch(B, V, C, "random", 100, cap_hi, 5, 500, seed=seed)
+    p = rng.random((B, V, V, C)).astype(np.float32) * 0.5 + 0.01
+    p[b["edges_target"] == 1] = 0.9
+    y = np.log(p).astype(np.float32)
+    max_iter = 5
+    perms = np.stack([rng.permutation(C) for _ in range(B * max_iter)]).astype(np.int32)
+    rp, rl, rf, ratt, used = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, algo, True, max_iter, perms)
+    a = _make(algo, y, b["edges_capacity"], b["commodities"], K, True, max_iter, dev)
+    it = iter([torch.from_numpy(q.astype(np.int64)) for q in perms])
+    orig = torch.randperm
+    torch.randperm = lambda n, *args, **kw: next(it, torch.arange(n))
+    try:
+        a.search()
+    finally:
+        torch.randperm = orig
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+    if algo in ("standard", "greedy"):
+        assert int(a.attempts.sum()) == used
