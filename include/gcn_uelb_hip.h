@@ -173,7 +173,11 @@ int gcn_loss_edges_bwd(int B, int V, int C, const float* logits, const long long
  *     the graphs' adjacency lists (edges with non-zero capacity, up to 24 per node on average) and the scores
  *     gathered per list entry, built by two launches of their own: a step then examines the beams' out-edges
  *     instead of K x V entries, in the same order and with the same tie-break; graphs with more edges, more than
- *     2048 nodes, K > 64, or a smaller workspace keep the dense scan.
+ *     2048 nodes, K > 64, or a smaller workspace keep the dense scan.  On graphs whose capacity matrix exceeds
+ *     32 KiB, in strict mode with 16 commodities or more and the full workspace, the ordered pass runs in rounds of
+ *     two launches (walk until a commodity's predicate differs from the capacities the first pass searched against,
+ *     then search all remaining commodities against the capacities reached); the state between the launches
+ *     (position, attempt, working capacities per list entry) lives in the workspace too.  Same paths, bit for bit.
  * ---------------------------------------------------------------------------------------------- */
 size_t gcn_beam_ws_bytes(int B, int V, int C, int K);
 int gcn_beam_search(int B, int V, int C, int K, int algorithm, int mode_strict, int max_iter, const float* y,
