@@ -704,6 +704,7 @@ struct ModelBwdWs {
     float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
     int* emb_cnt;
     int head_blk, S_h, emb_blk;
+    bool head_fused;                // the first MLP weight gradient is formed inside the head kernel (strip path, one hidden layer)
 };
 ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     ModelBwdWs w;
@@ -718,7 +719,10 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     }
     w.de = b.f(eh);
     w.dx = b.f(p.d.Rn * p.d.H);
-    w.eL = p.NHID > 0 ? b.f(eh) : nullptr;         // output of the last conv layer, operand of the first MLP weight gradient
+    w.head_fused = p.whead && p.NHID == 1 && p.d.MT >= 1 && p.d.MT <= 4;
+    if (tune_env("GCN_TUNE_NOHEADFUSE")) w.head_fused = false;
+    // output of the last conv layer, operand of the first MLP weight gradient (not stored when the head kernel forms that product)
+    w.eL = (p.NHID > 0 && !w.head_fused) ? b.f(eh) : nullptr;
     // with one hidden layer the pre-activation stash aliases the layers' det buffer (the head finishes
     // before layer L-1 starts); deeper MLPs get NHID contiguous slabs of their own
     w.dpre_stash = p.NHID > 1 ? b.f((size_t)p.NHID * eh) : nullptr;
@@ -726,7 +730,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     w.head_blk = head_blocks((p.d.Re + 15) / 16, false, p.d.H);
     w.wpartial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * (size_t)((p.voc * p.d.H + p.voc + 3) & ~3));
     w.S_h = tn_slices(p.d.Re, p.d.H);
-    w.tn_h = b.f((size_t)w.S_h * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));
+    w.tn_h = b.f((size_t)std::max(w.S_h, w.head_fused ? w.head_blk : 0) * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));
     w.emb_blk = wave_blocks((p.d.Re + 15) / 16);
     w.embpart = b.f((size_t)w.emb_blk * GCN_WAVES_PER_BLOCK * p.d.H);
     w.emb_g = b.f((size_t)p.d.B * p.d.V * p.d.H);
@@ -761,7 +765,7 @@ template <int MT, int NHID>
 void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadParams& hp, const EdgeSrc& src, const NextBn& next,
                      float* e_stash, const float* cap, const long long* y_edges, const float* edge_cw, const float* loss_out,
                      const float* dloss, const float* dy_pred, float* de, float* dpre, float* hst, float* wpartial,
-                     const unsigned long long* rng, int blocks, const ZeroJobs& z, const float* hidWt, hipStream_t st) {
+                     const unsigned long long* rng, int blocks, const ZeroJobs& z, const float* hidWt, float* wg_out, hipStream_t st) {
     if (p.whead) {
         if constexpr (NHID <= 1) {
             if constexpr (MT == 0)
@@ -772,7 +776,7 @@ void launch_head_bwd(const ModelPlan& p, const gcn_model_desc* m, const HeadPara
                 k_head_bwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, hidWt, src, next, e_stash, cap,
                                                                   m->mask_invalid_edges, m->has_labels ? y_edges : nullptr, edge_cw,
                                                                   loss_out, dloss, dy_pred, de, dpre, wpartial, rng, 1000, m->p_mlp,
-                                                                  m->training, z);
+                                                                  m->training, z, wg_out);
         }
     } else if constexpr (MT != 0)
     k_head_bwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, next, e_stash, cap,
@@ -1134,9 +1138,13 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
         }
     } else {
         GCN_PROF_PRE("k_head_bwd");
-        DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.eL, cap, y_edges, edge_cw, loss_out,
-                                                                          dloss, dy_pred, W.de, dpre_all, W.h_stash, W.wpartial, rng,
-                                                                          W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2, st))));
+        // strip path with one hidden layer: its weight-gradient product is part of the head kernel (one slab per workgroup
+        // in tn_h) and neither the head's input nor the pre-activation gradient is stored
+        DISPATCH_MT(d.MT, DISPATCH_NHID(p.NHID, (launch_head_bwd<MT, NHID>(p, m, hp, src, hnext, W.head_fused ? nullptr : W.eL, cap, y_edges,
+                                                                          edge_cw, loss_out, dloss, dy_pred, W.de,
+                                                                          W.head_fused ? nullptr : dpre_all, W.h_stash, W.wpartial, rng,
+                                                                          W.head_blk, hz, W.wT + (size_t)4 * p.L * hh2,
+                                                                          W.head_fused ? W.tn_h : nullptr, st))));
         GCN_CHECK_LAUNCH("k_head_bwd");
     }
     int npart_e = W.head_blk, npart_x = 1;
@@ -1147,12 +1155,12 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     for (int k = 0; k < p.NHID; ++k) {
         hpr.X[k] = dpre_all + (size_t)k * eh;
         hpr.Y[k] = k == 0 ? W.eL : W.h_stash + (size_t)(k - 1) * eh;
-        hpr.rows[k] = d.Re; hpr.nslices[k] = W.S_h; hpr.out[k] = W.tn_h + (size_t)k * slab; hpr.out_stride[k] = (size_t)p.NHID * slab;
+        hpr.rows[k] = d.Re; hpr.nslices[k] = W.head_fused ? 0 : W.S_h; hpr.out[k] = W.tn_h + (size_t)k * slab; hpr.out_stride[k] = (size_t)p.NHID * slab;
     }
     ReduceJob head_tn_job = {};
     bool head_tn_pending = false;
     if (p.NHID > 0) {
-        head_tn_job.partial = W.tn_h; head_tn_job.nP = W.S_h; head_tn_job.ncols = p.NHID * slab;
+        head_tn_job.partial = W.tn_h; head_tn_job.nP = W.head_fused ? W.head_blk : W.S_h; head_tn_job.ncols = p.NHID * slab;
         ReduceDst& rd = head_tn_job.rd;
         rd.n = 2 * p.NHID;
         for (int k = 0; k < p.NHID; ++k) {

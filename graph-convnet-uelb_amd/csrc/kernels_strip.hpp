@@ -1001,14 +1001,17 @@ __global__ __launch_bounds__(64 * MT) void k_head_fwd3(
 }
 
 // Backward (same outputs as k_head_bwd, NHID <= 1); wpartial has one row per workgroup, hidWt is the transposed
-// hidden weight.
+// hidden weight.  wg_out (nullable, NHID = 1): the workgroup also forms its share of the hidden layer's weight gradient
+// dpre^T e (one H x H + H slab per workgroup, rows = output channels, then the bias sums) from the two tiles it has in
+// LDS anyway; the caller then passes null stashes and neither the head's input nor dpre goes to memory.
 template <int MT, int NHID>
 __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ hidWt, EdgeSrc src, NextBn next,
     float* __restrict__ e_stash, const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
     const float* __restrict__ edge_cw, const float* __restrict__ loss_out, const float* __restrict__ dloss,
     const float* __restrict__ dy_pred, float* __restrict__ de, float* __restrict__ dpre_stash,
-    float* __restrict__ wpartial, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z) {
+    float* __restrict__ wpartial, const unsigned long long* __restrict__ rng, int stream_id0, float p, int training, ZeroJobs z,
+    float* __restrict__ wg_out) {
     static_assert(NHID <= 1, "at most one hidden layer");
     using GM = StripGeom<MT>;
     __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
@@ -1036,6 +1039,11 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     const float gl = has_loss ? (dloss ? dloss[0] : 1.f) / loss_out[1] : 0.f;
     f32x4 gw0 = f4zero(), gw1 = f4zero(), na1 = f4zero(), na2 = f4zero();
     float gb0 = 0.f, gb1 = 0.f;
+    const bool fuse = NHID && wg_out != nullptr;
+    f32x4 wacc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wacc[m] = f4zero();
+    float bsum = 0.f;
     const size_t ntiles = (rows + 15) / 16;
     int buf = 0;
     __syncthreads();
@@ -1109,12 +1117,24 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
             gw1[r] += d1 * h[r];
             dp[r] = (d0 * w0[r] + d1 * w1[r]) * dmul[r];
         }
-        if (NHID && rvalid && bcol_ok) st4(dpre_stash + row * H + bcol, dp);
+        if (NHID && dpre_stash != nullptr && rvalid && bcol_ok) st4(dpre_stash + row * H + bcol, dp);
         f32x4 dv = dp;
         if (NHID) {
             st4(&tdp[buf][rs][bcol], dp);
             __syncthreads();
             dv = strip_gemm<MT>(tdp[buf], wft, rs, q);
+            if (fuse) {
+                // dW[n][kc] += sum over the tile's rows of dpre[row][n] * e[row][kc] (A[i = n][kk = row], B[kk = row][j = kc]);
+                // rows beyond the tensor hold zeros in both tiles
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const float av = tdp[buf][4 * st + q][16 * w + rs];
+                    bsum += av;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        wacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[buf][4 * st + q][16 * m + rs], wacc[m], 0, 0, 0);
+                }
+            }
         }
         if (rvalid && bcol_ok) {
             st4(de + row * H + bcol, dv);
@@ -1149,5 +1169,18 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     if (w == 0) {
         gb0 = red16(gb0); gb1 = red16(gb1);      // lanes with q != 0 hold zeros
         if (t == 0) { wp[voc * H] = gb0; if (voc > 1) wp[voc * H + 1] = gb1; }
+    }
+    if (fuse) {
+        float* out = wg_out + (size_t)blockIdx.x * ((size_t)H * H + H);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = 16 * w + 4 * q + r, kc = 16 * m + rs;
+                if (nn < H && kc < H) out[(size_t)nn * H + kc] = wacc[m][r];
+            }
+        const float bs = redq(bsum);
+        const int n = 16 * w + rs;
+        if (q == 0 && n < H) out[(size_t)H * H + n] = bs;
     }
 }
