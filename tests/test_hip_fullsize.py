@@ -146,6 +146,20 @@ def test_full_config_forward_backward(name):
     _check_config(name, CONFIGS[name]["B"])
 
 
+@pytest.mark.parametrize("name,B", [("nsfnet_10_commodities", 160), ("default2", 40)])
+def test_shipped_config_at_a_batch_that_selects_the_two_block_kernels(name, B):
+    """From 300,000 edge rows on the library switches to the edge kernels with two column blocks per wavefront (weight
+    gradient fused, row-chunk length from the busiest CU's step count): the shipped shapes at 8 and 2 times their batch
+    cross that line (313,600 rows of one 14-row tile per node; 320,000 rows with a ragged third tile).  Same strict
+    check as at the shipped batch, all layers."""
+    from src.common.synthetic import CONFIGS
+    from src.gcn.hip import lib as L
+    _dev()
+    c = CONFIGS[name]
+    assert L.layer_plan(B, c["V"], c["C"], c["H"])["two_blocks"] and not L.layer_plan(c["B"], c["V"], c["C"], c["H"])["two_blocks"]
+    _check_config(name, B)
+
+
 def test_config4_100_nodes_50_commodities_h300_all_30_layers():
     """Benchmark configuration 4 (BASELINE.json) on its own workload: V = 100, C = 50, H = 300, L = 30 (all layers), one graph per GPU:
     500,000 edge rows, a 600 MB edge tensor per layer in float32."""
