@@ -2,7 +2,8 @@
 # End-of-round measurement set (on the GPU box, from the repo root): bash tools/r02_measure.sh
 # Per configuration an eager rocprofv3 kernel trace and a graph-replay bench line; the HBM traffic passes of the edge
 # kernels for three configurations; instruction-mix passes (counters only, one set per run) at nsfnet_10 and at
-# 200 nodes x 100 commodities; the MFMA pass of the H = 300 configuration.  Everything lands under gpurun_out/r02/.
+# 200 nodes x 100 commodities; the MFMA pass of the H = 300 configuration; the default bench run.  Everything lands under
+# gpurun_out/r02/ (copy what is to be kept into profiles/ as r02_*).
 out=gpurun_out/r02
 mkdir -p $out
 export TMPDIR=/tmp
@@ -29,4 +30,9 @@ done
 step "MFMA pass H = 300"
 bash tools/pmc_mfma.sh r02_mfma_h300 synthetic_100n_50c_h300_l30 "k_edge|k_gemm_tn" || exit 1
 cp gpurun_out/pmc_r02_mfma_h300.txt $out/pmc_mfma_h300.txt
+step "default bench run (with the traffic table just taken)"
+cp $out/pmc_traffic.json profiles/pmc_traffic.json
+timeout -k 10 600 python -u bench.py > $out/bench_default_run.log 2>&1 || { echo "default run failed"; tail -5 $out/bench_default_run.log; exit 1; }
+tail -1 $out/bench_default_run.log > $out/bench_default_run.json
+cut -c1-400 $out/bench_default_run.json
 echo done
