@@ -256,8 +256,8 @@ struct LayerFwdWs {
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
     w.nblk = range_blocks(d.Rn, d.grid_f);
-    if (d.two_blocks) w.nblk = d.grid_f;                    // k_edge_fwd4 deals its units by XCD: a multiple of 8 workgroups
-    if (const char* e = tune_env("GCN_TUNE_GRID_F")) w.nblk = d.two_blocks ? std::max(8, std::min(atoi(e), 2048) & ~7) : range_blocks(d.Rn, std::min(atoi(e), 2048));
+    if (d.MT <= 4) w.nblk = d.grid_f;                       // the strip forward kernels deal their units by XCD: a multiple of 8 workgroups
+    if (const char* e = tune_env("GCN_TUNE_GRID_F")) w.nblk = d.MT <= 4 ? std::max(8, std::min(atoi(e), 2048) & ~7) : range_blocks(d.Rn, std::min(atoi(e), 2048));
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
     w.partial = b.f((size_t)w.nblk * 4 * d.H);
