@@ -101,3 +101,25 @@ def test_model_errors_match_reference_behaviour():
     assert len(layer.hip_parameters()) == 12
     with pytest.raises(GcnHipError):
         layer(torch.zeros(1, 2, 1, 8), torch.zeros(1, 2, 2, 1, 8))
+
+
+def test_launch_plan_is_sane_over_a_grid_of_shapes():
+    """gcn_layer_plan is host code: row chunks of equal length that cover V, grids within the partial-row buffers
+    (2048 rows), a multiple of 8 forward workgroups on the strip path (the forward kernels deal their units to the 8
+    XCDs), and the two-block kernels exactly from 300,000 edge rows on at 32 / 64 channels."""
+    from src.gcn.hip import lib as L
+    L.load()
+    for H in (16, 32, 48, 64, 128, 300):
+        for (B, V, C) in [(1, 5, 1), (2, 14, 4), (20, 14, 10), (20, 14, 20), (20, 40, 5), (40, 40, 5), (80, 14, 10),
+                          (160, 14, 10), (320, 14, 10), (1, 100, 50), (2, 100, 50), (1, 200, 100), (4, 200, 100), (3, 33, 7)]:
+            plan = L.layer_plan(B, V, C, H)
+            it, n = plan["row_chunk"], plan["n_chunks"]
+            assert 1 <= it <= V and n == -(-V // it), (B, V, C, H, plan)
+            assert n * it - V < it                                  # the last chunk is not empty
+            assert -(-V // n) == it or H > 64                       # equal chunks (the wide path rounds to threes)
+            assert plan["j_tiles"] == -(-V // 16)
+            assert 1 <= plan["grid_fwd"] <= 2048 and 1 <= plan["grid_bwd"] <= 2048
+            assert plan["wide"] == (H > 64)
+            if H <= 64:
+                assert plan["grid_fwd"] % 8 == 0
+            assert plan["two_blocks"] == (H in (32, 64) and B * V * V * C >= 300000), (B, V, C, H, plan)
