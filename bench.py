@@ -18,12 +18,19 @@ Besides the headline value the line carries
                  threads and one), rank 0, N = 1 only;
   batch_sweep  - the same step at B = 20, 80, 320 graphs (headline workload only);
   beam_search  - graphs/sec of the batched GPU beam-search decode next to the C oracle (N = 1 only), also at
-                 200 nodes x 100 commodities with the bytes of scores read per second.
+                 200 nodes x 100 commodities with the bytes of scores read per second;
+  large_configs - the two large benchmark configurations (100 nodes x 50 commodities at H = 300, L = 30 and 200 nodes x
+                 100 commodities at H = 64, L = 10) at one graph per GPU: ms per step and the event-timed edge kernels.
+
+Started as plain `python bench.py --gpus N` with N > 1 (no launcher, WORLD_SIZE unset) the script starts its N ranks
+itself, one child process per GPU, before it touches the GPU, prints rank 0's JSON line and exits with the ranks' status.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,7 +53,10 @@ class Cfg(dict):
 def build_model(shape, device):
     from src.gcn.models.gcn_model import ResidualGatedGCNModel
     cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
-              hidden_dim=shape["H"], num_layers=shape["L"], mlp_layers=2, aggregation="mean", dropout_rate=0.5)
+              hidden_dim=shape["H"], num_layers=shape["L"], mlp_layers=2, aggregation="mean",
+              # the key the reference's config files carry (nsfnet_10_commodities.json:38); the model reads it and, like the
+              # reference, never uses it: the layers drop with p = 0.3 and the MLP with p = 0.2 (gcn_model.py:31,39,42)
+              dropout_rate=0.5)
     torch.manual_seed(0)                      # identical initial weights on every rank
     return ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(device)
 
@@ -169,6 +179,116 @@ def batch_sweep(name, shape, device, rank, batches=(20, 80, 320), steps=20):
     return {"workload": name, "mode": "train (dropout on), fwd+bwd, HIP graph replay", "points": out}
 
 
+def time_kernels(eager, lib, prefixes, nprof):
+    """Average launch duration (ms) of the kernels whose names start with each prefix, from the kernels' own begin / end
+    time stamps on the launch stream (gcn_prof_begin / gcn_prof_end), over nprof eager steps per prefix."""
+    out = {}
+    for pre in prefixes:
+        lib.gcn_prof_begin(pre.encode())
+        for _ in range(nprof):
+            eager.step()
+        tot_ms, n = ctypes.c_double(0), ctypes.c_int(0)
+        lib.gcn_prof_end(ctypes.byref(tot_ms), ctypes.byref(n))
+        out[pre] = (tot_ms.value / max(n.value, 1), int(n.value))
+    return out
+
+
+def edge_kernel_names(plan, H):
+    """(forward, backward) edge kernel of a launch plan: the family the library picks for this size."""
+    if H > 64:
+        return "k_edge_fwd_ws", "k_edge_bwd_ws"
+    return ("k_edge_fwd4", "k_edge_bwd4") if plan["two_blocks"] else ("k_edge_fwd3", "k_edge_bwd3")
+
+
+def edge_kernel_roofline(kernel, forward, avg_ms, nlaunch, B, V, C, H, two_blocks):
+    """Roofline entry of one edge kernel launch (= one layer over the whole batch).  HBM bound up to 64 channels:
+    algorithmic bytes 8 H (R_e + R_n) forward (read e, write e_tmp) and 12 H (R_e + R_n) backward (read de and the saved
+    activation, write de_in); above 64 channels the H x H product per row outweighs the row's bytes (2 H^2 flop against
+    12 H bytes: 50 flop per byte at H = 300, the balance point of fp32 MFMA against HBM is about 20): matrix-pipe bound,
+    priced against the dense fp32 MFMA peak whatever arithmetic the kernel uses to reach fp32 accuracy."""
+    Re, Rn = B * V * V * C, B * V * C
+    algo_bytes = (8.0 if forward else 12.0) * H * (Re + Rn)
+    gbps = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(gbps / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": algo_bytes,
+         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": nlaunch}
+    if H <= 64:
+        # what this kernel family itself must move per launch (the fused forms read more than the algorithmic minimum):
+        # forward reads the previous layer's e_tmp and e_in and writes e_in and e_tmp (4 edge tensors); the one-block
+        # backward reads de, e_tmp and the lower layer's e_tmp and writes de and det (5), the two-block backward reads
+        # de, e_tmp, e_in and the lower layer's e_tmp and writes de (5)
+        model = (16.0 if forward else 20.0) * H * Re
+        r["kernel_model_bytes_per_launch"] = model
+        r["kernel_model_GBps"] = round(model / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0
+        r["kernel_family"] = "two column blocks per wavefront" if two_blocks else "one column block per wavefront"
+    else:
+        flops = 2.0 * H * H * Re
+        tf = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        r.update({"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops,
+                  "hbm_GBps": round(gbps, 1),
+                  "arithmetic": "fp32 operands cut into three bf16 pieces, six v_mfma_f32_16x16x32_bf16 products per block, "
+                                "fp32 accumulation (fp32-accurate; no fp32 MFMA issued)"})
+    return r
+
+
+def large_configs(device, rank):
+    """The two large benchmark configurations at one graph per GPU: 2 warm-up + 3 timed steps of HIP graph replay, then
+    the edge kernels timed by their own time stamps in an eager pass."""
+    from src.common.synthetic import CONFIGS, make_batch
+    from src.gcn.hip import lib as L
+    from src.gcn.hip.train_step import HipTrainStep
+    lib = L.load()
+    out = {}
+    for name in ("synthetic_100n_50c_h300_l30", "synthetic_200n_100c"):
+        try:
+            shape = dict(CONFIGS[name])
+            B = 1
+            V, C, H, Lr = shape["V"], shape["C"], shape["H"], shape["L"]
+            batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
+                               seed=1234 + rank)
+            model = build_model(shape, device).train()
+            args = (batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
+                    batch["edges_target"], batch["edge_cw"])
+            step = HipTrainStep(model, B, device, use_graph=True)
+            step.load_batch(*args)
+            for _ in range(2):
+                step.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            loss = float(step.loss_out[0].item())
+            del step
+            torch.cuda.empty_cache()
+            eager = HipTrainStep(model, B, device, use_graph=False)
+            eager.load_batch(*args)
+            eager.step()
+            plan = L.layer_plan(B, V, C, H)
+            kf, kb = edge_kernel_names(plan, H)
+            names = [kf, kb] + (["k_gemm_tn"] if H > 64 else [])
+            tk = time_kernels(eager, lib, names, 1)
+            step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
+            e = {"workload": f"V={V} C={C} H={H} L={Lr}, {B} graph per GPU, train mode, fwd+bwd, HIP graph replay",
+                 "ms_per_step": round(ms, 3), "graphs_per_s": round(B / ms * 1e3, 3), "steps": 3, "warmup": 2,
+                 "loss": round(loss, 5),
+                 "whole_step_algorithmic_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                 "edge_bwd": edge_kernel_roofline(kb, False, tk[kb][0], tk[kb][1], B, V, C, H, plan["two_blocks"]),
+                 "edge_fwd": edge_kernel_roofline(kf, True, tk[kf][0], tk[kf][1], B, V, C, H, plan["two_blocks"])}
+            if H > 64:
+                ms_tn, n_tn = tk["k_gemm_tn"]
+                e["weight_gradient"] = {"kernel": "k_gemm_tn_w (four products per launch: the edge product and three node products)",
+                                        "avg_launch_us": round(ms_tn * 1e3, 2), "launches_timed": n_tn}
+            out[name] = e
+            del eager, model
+            torch.cuda.empty_cache()
+        except Exception as ex:      # the headline metric must still be reported
+            out[name] = {"error": repr(ex)}
+    return out
+
+
 def beam_bench_large(device, B=2, V=200, C=100, K=10):
     """Beam-search decode at the largest benchmark configuration (BASELINE.json: 200 nodes x 100 commodities, K = 10, strict,
     deterministic): graphs/s, and the bytes of the score tensor y the search reads (4 V^2 bytes per commodity) over the
@@ -289,6 +409,36 @@ def _stage(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: one child process per GPU, started before this process makes any
+    GPU call (importing torch does not initialise the device).  Rank 0's stdout is passed through; the exit status is
+    the first non-zero status of a rank (the others are then stopped), 0 if all ranks succeed."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+                for q in live:          # a rank failed: the others would wait in a collective forever
+                    q.terminate()
+    return status if status >= 0 else 128 - status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,10 +451,13 @@ def main():
     ap.add_argument("--skip-beam", action="store_true")
     ap.add_argument("--skip-sweep", action="store_true", help="skip the batch sweep (B = 20, 80, 320) of the headline workload")
     ap.add_argument("--skip-opt", action="store_true", help="skip the extra leg that adds the optimizer step")
+    ap.add_argument("--skip-large", action="store_true", help="skip the large_configs legs (the two large configurations at one graph per GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the broadcast / all-reduce even with one rank "
                          "(executes the RCCL path on a single GPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     from src.common.synthetic import CONFIGS, make_batch
     from src.gcn.hip import lib as L
@@ -315,8 +468,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     dist = None
     backend = None
     if world > 1 or args.force_dist:
@@ -383,6 +536,25 @@ def main():
         D.allreduce_max_(t)
         elapsed = float(t.item())
     _stage("timed steps done")
+    # ---- the gradient all-reduce on its own: time between the end of the step's last kernel and the end of the
+    # collective, over steps of their own (outside the headline's timed region)
+    allreduce_ms = None
+    if dist is not None:
+        n_ar = max(3, min(args.steps, 20))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ar)]
+        wall = 0.0
+        for e0, e1 in ev:
+            step.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e0.record()
+            D.allreduce_mean_(step.flat_grad)
+            e1.record()
+            torch.cuda.synchronize()
+            wall += time.perf_counter() - t1
+        t = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / n_ar, wall / n_ar * 1e3], dtype=torch.float64, device=device)
+        D.allreduce_max_(t)
+        allreduce_ms = [float(v) for v in t.tolist()]
     loss = float(step.loss_out[0].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
@@ -420,8 +592,9 @@ def main():
                     "ms_per_step": round(el / args.steps * 1e3, 4), "graphs_per_s": round(world * B * args.steps / el, 1)}
         _stage("steps with optimizer done")
 
-    # ---- dominant kernel, timed with HIP events around each of its launches (eager pass, rank 0)
-    roofline = None
+    # ---- the edge kernels, timed by their own begin / end time stamps on the launch stream (eager pass, rank 0);
+    # `roofline` is the dominant one (edge backward), `roofline_fwd` the forward kernel of the same layer
+    roofline = roofline_fwd = None
     if rank == 0:
         lib = L.load()
         eager = HipTrainStep(model, B, device, use_graph=False)
@@ -430,36 +603,23 @@ def main():
         for _ in range(3):
             eager.step()
         torch.cuda.synchronize()
-        dominant = DOMINANT_KERNEL if H <= 64 else "k_edge_bwd_w"
-        lib.gcn_prof_begin(dominant.encode())
-        nprof = max(5, min(args.steps, 20))
-        for _ in range(nprof):
-            eager.step()
-        tot_ms, n = ctypes.c_double(0), ctypes.c_int(0)
-        lib.gcn_prof_end(ctypes.byref(tot_ms), ctypes.byref(n))
-        avg_ms = tot_ms.value / max(n.value, 1)
-        Re, Rn = B * V * V * C, B * V * C
-        traffic, traffic_stale = measured_traffic(args.config, B, dominant)
-        # one launch = the edge backward of one layer: read d e_new, read the saved activation, write d e_in
-        algo_bytes = 12.0 * H * (Re + Rn)
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        step_bytes = (20.0 * Lr + 20.0) * H * Re
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_stale": traffic_stale,
-                    "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
-                    "launches_timed": int(n.value),
-                    "whole_step_algorithmic_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)}
-        if H > 64:
-            # above 64 channels the H x H product per edge row outweighs the row's bytes (2 H^2 flop against 12 H
-            # bytes: 50 flop per byte at H = 300, the fp32 MFMA / HBM balance point is about 20): matrix-pipe bound
-            algo_flops = 2.0 * H * H * Re
-            tflops = algo_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            roofline.update({"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": algo_flops,
-                             "hbm_GBps": round(achieved, 1)})
+        plan = L.layer_plan(B, V, C, H)
+        kf, kb = edge_kernel_names(plan, H)
+        nprof = max(5, min(args.steps, 20)) if H <= 64 else 2
+        tk = time_kernels(eager, lib, [kb, kf], nprof)
+        roofline = edge_kernel_roofline(kb, False, tk[kb][0], tk[kb][1], B, V, C, H, plan["two_blocks"])
+        roofline_fwd = edge_kernel_roofline(kf, True, tk[kf][0], tk[kf][1], B, V, C, H, plan["two_blocks"])
+        traffic, traffic_stale = measured_traffic(args.config, B, kb)
+        roofline["traffic"] = traffic
+        roofline["traffic_stale"] = traffic_stale
+        traffic, traffic_stale = measured_traffic(args.config, B, kf)
+        roofline_fwd["traffic"] = traffic
+        roofline_fwd["traffic_stale"] = traffic_stale
+        step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
+        roofline["whole_step_algorithmic_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore
             p.grad = gview
+        del eager
 
     out = None
     if rank == 0:
@@ -476,8 +636,12 @@ def main():
             "rccl_ranks": D.rccl_ranks(),
             "gradient_allreduce": None if dist is None else {
                 "backend": backend, "op": "all_reduce AVG" if backend == "nccl" else "all_reduce SUM, host-staged",
-                "bytes": int(step.flat_grad.numel()) * 4, "per_step": 1},
-            "roofline": roofline, "with_optimizer": with_opt,
+                "bytes": int(step.flat_grad.numel()) * 4, "per_step": 1,
+                # max over ranks: device time between events recorded around the collective on the step's stream, and
+                # host wall time of the same stretch (collective launch to completion), step already finished
+                "ms_per_step": round(allreduce_ms[0], 4), "wall_ms_per_step": round(allreduce_ms[1], 4),
+                "overlap": "none (one message after the step's last kernel)"},
+            "roofline": roofline, "roofline_fwd": roofline_fwd, "with_optimizer": with_opt,
         }
         if world == 1 and not args.skip_cpu:
             out["cpu_baseline"] = cpu_baseline(shape, batch)
@@ -486,6 +650,10 @@ def main():
                 out["batch_sweep"] = batch_sweep(args.config, shape, device, rank)
             except Exception as ex:      # the headline metric must still be reported
                 out["batch_sweep"] = {"error": repr(ex)}
+        if world == 1 and not args.skip_large and args.config == "nsfnet_10_commodities" and not args.batch:
+            del step
+            torch.cuda.empty_cache()
+            out["large_configs"] = large_configs(device, rank)
         if world == 1 and not args.skip_beam:
             try:
                 out["beam_search_200n_100c"] = beam_bench_large(device)

@@ -20,6 +20,7 @@
 #include "kernels_strip.hpp"
 #include "kernels_strip2.hpp"
 #include "kernels_wide.hpp"
+#include "kernels_wide_bf.hpp"
 #include "sampler.hpp"
 #include "dataset.hpp"
 
@@ -92,14 +93,15 @@ inline void prof_post(hipStream_t st) {
 #define GCN_STREAM st
 
 // launch of one of the main kernels, timed by its own time stamps when the profiler is armed for its name
-#define GCN_LAUNCH_TIMED(name, kern, grid, block, ...)                                            \
+#define GCN_LAUNCH_TIMED_LDS(name, kern, grid, block, lds, ...)                                   \
     do {                                                                                         \
         hipEvent_t es_ = nullptr, ee_ = nullptr;                                                 \
         prof_ext(name, &es_, &ee_);                                                              \
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (hipStream_t)GCN_STREAM, es_, ee_, 0, __VA_ARGS__); \
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, (hipStream_t)GCN_STREAM, es_, ee_, 0, __VA_ARGS__); \
         hipError_t e_ = hipGetLastError();                                                       \
         if (e_ != hipSuccess) return fail(-3, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
+#define GCN_LAUNCH_TIMED(name, kern, grid, block, ...) GCN_LAUNCH_TIMED_LDS(name, kern, grid, block, 0, __VA_ARGS__)
 
 struct Dims {
     int B, V, C, H;
@@ -177,8 +179,9 @@ Dims make_dims(int B, int V, int C, int H) {
                 if (bestc < 0 || c < bestc) { bestc = c; d.IT = it; }
             }
         }
-    } else if (d.IT > 3) {
-        d.IT = std::min(V, (d.IT + 2) / 3 * 3);             // the wide kernel walks the rows of a chunk three at a time
+    } else {
+        if (d.IT > SNS) d.IT = std::min(V, (d.IT + SNS - 1) / SNS * SNS);   // the wide kernel walks the rows of a chunk SNS at a time
+        d.grid_f = d.grid_b = 256;                          // one 512-thread workgroup per CU (kernels_wide_bf.hpp)
     }
     if (const char* e = tune_env("GCN_TUNE_IT")) d.IT = std::max(1, std::min(V, atoi(e)));
     d.nit = (V + d.IT - 1) / d.IT;
@@ -252,6 +255,7 @@ LayerSaved carve_saved(const Dims& d, float* p) {
 struct LayerFwdWs {
     float *Ux, *Ve, *partial;
     int nblk;
+    u32x4* wsplit;      // above 64 channels: bf16 planes of edge_feat.U.weight (kernels_wide_bf.hpp)
 };
 LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     LayerFwdWs w;
@@ -261,6 +265,7 @@ LayerFwdWs carve_fwd_ws(const Dims& d, Bump& b) {
     w.Ux = b.f(d.Rn * d.H);
     w.Ve = b.f(d.Rn * d.H);
     w.partial = b.f((size_t)w.nblk * 4 * d.H);
+    w.wsplit = d.MT > 4 ? (u32x4*)b.raw(split_weight_bytes(d.H)) : nullptr;
     return w;
 }
 
@@ -299,6 +304,7 @@ struct LayerBwdWs {
     float *det, *bpart_e, *bpart_x, *bstats_e, *bstats_x, *dxtmp, *rowpart, *colVe, *colVn, *dVe, *dVn;
     float *tn_e, *tn_n;
     int S_e, S_n;       // partial slabs of the edge / node weight-gradient products
+    u32x4* wsplit;      // above 64 channels: bf16 planes of edge_feat.U.weight^T (kernels_wide_bf.hpp)
 };
 LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
     LayerBwdWs w;
@@ -320,6 +326,7 @@ LayerBwdWs carve_bwd_ws(const Dims& d, Bump& b) {
     const size_t slab = (size_t)d.H * d.H + d.H;
     w.tn_e = b.f((size_t)w.S_e * slab);
     w.tn_n = b.f((size_t)w.S_n * 3 * slab);
+    w.wsplit = d.MT > 4 ? (u32x4*)b.raw(split_weight_bytes(d.H)) : nullptr;
     return w;
 }
 
@@ -346,6 +353,29 @@ EdgeSrc make_edge_src(const PrevLayer& pv, const float* e_in, float* e_out, int 
         s.mode = 0; s.e_in = e_in;
     }
     return s;
+}
+
+// bf16 planes of n H x H matrices (at most 64 per launch), optionally of their transposes
+int launch_split_weights(const float* const* src, u32x4* const* dst, int n, int H, bool transposed, hipStream_t st) {
+    const int frags = ((H + 15) / 16) * split_nkb(H);
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        SplitList sl = {};
+        const int m = std::min(64, n - i0);
+        for (int k = 0; k < m; ++k) { sl.src[k] = src[i0 + k]; sl.dst[k] = dst[i0 + k]; }
+        sl.transposed = transposed ? 1 : 0;
+        GCN_PROF_PRE("k_split_weights");
+        k_split_weights<<<dim3((frags + 3) / 4, m, 1), 256, 0, st>>>(sl, H);
+        GCN_CHECK_LAUNCH("k_split_weights");
+    }
+    return 0;
+}
+// the edge kernels of kernels_wide_bf.hpp keep their step's rows in 3 SPB bytes of dynamic LDS: more than a kernel
+// gets without asking (set per call: the attribute belongs to the current device)
+template <typename K>
+int reserve_split_lds(K kern, const char* name) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SPB) != hipSuccess)
+        return fail(-3, "%s: cannot reserve %d bytes of LDS", name, 3 * SPB);
+    return 0;
 }
 
 // forward of one layer up to the BatchNorm statistics (the apply is left to the consumer)
@@ -376,7 +406,9 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         if (const char* e = tune_env("GCN_TUNE_PROBE")) a.probe = atoi(e);
         const bool one = d.V <= 16;
         if constexpr (MT == 0) {
-            GCN_LAUNCH_TIMED("k_edge_fwd_w", k_edge_fwd_w, W.nblk, 256, a);
+            a.WUs = W.wsplit;
+            if (int rc = reserve_split_lds(k_edge_fwd_ws, "k_edge_fwd_ws")) return rc;
+            GCN_LAUNCH_TIMED_LDS("k_edge_fwd_ws", k_edge_fwd_ws, W.nblk, STH, 3 * SPB, a);
         } else {
             bool launched = false;
             if constexpr (MT == 2 || MT == 4) {
@@ -417,6 +449,9 @@ int layer_fwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
                 const LayerSaved& S, const LayerFwdWs& W, hipStream_t st) {
     const int H = d.H;
     PrevLayer none = {};
+    if constexpr (MT == 0) {
+        if (int rc = launch_split_weights(&P[4], &W.wsplit, 1, H, false, st)) return rc;
+    }
     if (int rc = layer_fwd_core<MT>(d, agg, p, training, rng, none, x_in, nullptr, e_in, nullptr, P, S, W, st)) return rc;
     GCN_PROF_PRE("k_bn_apply(edges)");
     k_bn_apply<<<elem_blocks(d.Re * (H / 4)), 256, 0, st>>>(d.Re, H, S.e_tmp, e_in, S.stats, S.stats + H, P[10], P[11],
@@ -468,8 +503,11 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
         a.next.beta = nx.beta_e; a.next.drop_sid = 2 * nx.sid; a.next.partial = W.bpart_e;
     }
     const int blocks = edge_bwd_blocks(d);
-    if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_edge_bwd_w", k_edge_bwd_w, blocks, 256, a);
-    else {
+    if constexpr (MT == 0) {
+        a.WUs = W.wsplit;
+        if (int rc = reserve_split_lds(k_edge_bwd_ws, "k_edge_bwd_ws")) return rc;
+        GCN_LAUNCH_TIMED_LDS("k_edge_bwd_ws", k_edge_bwd_ws, blocks, STH, 3 * SPB, a);
+    } else {
         bool launched = false;
         if constexpr (MT == 2 || MT == 4) {
             if (d.two_blocks) {
@@ -598,6 +636,7 @@ int layer_bwd_t(const Dims& d, int agg, float p, int training, const unsigned lo
     const float* wT[4] = {P[0], P[2], P[4], P[6]};        // the strip kernels read the weights transposed themselves
     if constexpr (MT == 0) {
         if (int rc = transpose_layer_weights<MT>(P, wTbuf, wT, H, st)) return rc;
+        if (int rc = launch_split_weights(&P[4], &W.wsplit, 1, H, true, st)) return rc;
     }
     const int nblk_e = wave_blocks((d.Re + 15) / 16), nblk_x = wave_blocks((d.Rn + 15) / 16);
     GCN_PROF_PRE("k_bn_bwd_stats(edges)");
@@ -684,6 +723,7 @@ struct ModelFwdWs {
     int* count_rep;                 // [kCountReps][2][B*C]
     int head_blk;
     float* hid[2];                  // above 64 channels, MLPs with several hidden layers: outputs of the hidden layers before the last
+    unsigned char* wsplit_all;      // above 64 channels: bf16 planes of every layer's edge_feat.U.weight
 };
 ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     ModelFwdWs w;
@@ -694,6 +734,7 @@ ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     const bool deep_wide = p.d.MT > 4 && p.NHID > 1;
     w.hid[0] = deep_wide ? b.f(p.d.Re * p.d.H) : nullptr;
     w.hid[1] = deep_wide && p.NHID > 2 ? b.f(p.d.Re * p.d.H) : nullptr;
+    w.wsplit_all = p.d.MT > 4 ? (unsigned char*)b.raw((size_t)p.L * align_up(split_weight_bytes(p.d.H))) : nullptr;
     return w;
 }
 struct ModelBwdWs {
@@ -702,6 +743,7 @@ struct ModelBwdWs {
     float *nd2[3];                  // second set of dx_tmp / dVn / dVe: layer l's node backward writes while layer l+1's products read
     int* fin_counters;              // arrival counter of the in-kernel BatchNorm-backward finish (zero between launches)
     float *de, *dx, *eL, *dpre_stash, *h_stash, *wpartial, *tn_h, *embpart, *emb_g, *wT;
+    unsigned char* wsplit_all;      // above 64 channels: bf16 planes of every layer's edge_feat.U.weight^T
     int* emb_cnt;
     int head_blk, S_h, emb_blk;
     bool head_fused;                // the first MLP weight gradient is formed inside the head kernel (strip path, one hidden layer)
@@ -736,6 +778,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     w.emb_g = b.f((size_t)p.d.B * p.d.V * p.d.H);
     w.emb_cnt = (int*)b.raw((size_t)p.d.B * p.d.V * (size_t)p.n_emb * sizeof(int));
     w.wT = b.f((size_t)(4 * p.L + p.NHID) * p.d.H * p.d.H);
+    w.wsplit_all = p.d.MT > 4 ? (unsigned char*)b.raw((size_t)p.L * align_up(split_weight_bytes(p.d.H))) : nullptr;
     return w;
 }
 
@@ -1003,9 +1046,18 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
     k_embed_nodes<<<d.B * d.V, 64, 0, st>>>(d.V, d.C, H, m->n_emb, x_nodes, demand, P[0], P[1], x_act, ez,
                                             (m->advance_rng && rng) ? const_cast<unsigned long long*>(rng) : nullptr);
     GCN_CHECK_LAUNCH("k_embed_nodes");
+    const size_t wsplit_stride = align_up(split_weight_bytes(H));
+    if (d.MT > 4) {
+        std::vector<const float*> src;
+        std::vector<u32x4*> dst;
+        for (int l = 0; l < p.L; ++l) { src.push_back(P[3 + GCN_LAYER_NPARAMS * l + 4]); dst.push_back((u32x4*)(W.wsplit_all + (size_t)l * wsplit_stride)); }
+        if (int rc = launch_split_weights(src.data(), dst.data(), p.L, H, false, st)) return rc;
+    }
     for (int l = 0; l < p.L; ++l) {
         const LayerSaved S = carve_saved(d, saved + p.lsaved + (size_t)l * p.lsaved_each);
         const float* const* LP = P + 3 + GCN_LAYER_NPARAMS * l;
+        LayerFwdWs lw = W.lw;
+        if (d.MT > 4) lw.wsplit = (u32x4*)(W.wsplit_all + (size_t)l * wsplit_stride);
         PrevLayer pv = {};
         if (l == 0) { pv.kind = 2; pv.cap = cap; pv.we = P[2]; }
         else pv = prev_of(p, saved, P, l - 1);
@@ -1013,7 +1065,7 @@ int gcn_model_fwd(const gcn_model_desc* m, const float* cap, const float* demand
         // layer 0: x_act[0] was written by the embedding; later layers write their own input while applying layer l-1
         DISPATCH_MT(d.MT, rc = layer_fwd_core<MT>(d, m->aggregation, m->p_layer, m->training, rng, pv, x_act + (size_t)l * nh,
                                                   l == 0 ? nullptr : x_act + (size_t)l * nh, nullptr, e_act + (size_t)l * eh, LP, S,
-                                                  W.lw, st));
+                                                  lw, st));
         if (rc) return rc;
     }
     const HeadParams hp = head_params(p, P);
@@ -1075,6 +1127,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     const HeadParams hp = head_params(p, P);
     const int hbase = 3 + GCN_LAYER_NPARAMS * p.L;
     const int slab = H * H + H;
+    const size_t wsplit_stride = align_up(split_weight_bytes(H));
     // wide kernels only: transposed copies of every H x H weight used in an "X * W" product of the backward pass
     // (64 per launch); the strip kernels read the stored weights transposed
     if (d.MT > 4) {
@@ -1091,6 +1144,10 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             k_transpose_weights<<<n, GCN_BLOCK, 0, st>>>(tl, H);
             GCN_CHECK_LAUNCH("k_transpose_weights");
         }
+        std::vector<const float*> src;
+        std::vector<u32x4*> dst;
+        for (int l = 0; l < p.L; ++l) { src.push_back(P[3 + GCN_LAYER_NPARAMS * l + 4]); dst.push_back((u32x4*)(W.wsplit_all + (size_t)l * wsplit_stride)); }
+        if (int rc = launch_split_weights(src.data(), dst.data(), p.L, H, true, st)) return rc;
     }
     float* dpre_all = p.NHID == 1 ? W.lw.det : W.dpre_stash;   // [NHID][Re*H], see carve_model_bwd
     const PrevLayer last = prev_of(p, saved, P, p.L - 1);
@@ -1212,8 +1269,10 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                 nx.G = G + 3 + GCN_LAYER_NPARAMS * (l - 1);
             }
             int rc = 0;
+            LayerBwdWs lw = W.lw;
+            lw.wsplit = (u32x4*)(W.wsplit_all + (size_t)l * wsplit_stride);
             DISPATCH_MT(d.MT, rc = layer_bwd_data<MT>(d, m->aggregation, m->p_layer, m->training, rng, l, LP, wT, S, W.dx, W.de,
-                                                      e_act + (size_t)l * eh, nullptr, LG, W.lw, npart_e, npart_x, nx, false, st));
+                                                      e_act + (size_t)l * eh, nullptr, LG, lw, npart_e, npart_x, nx, false, st));
             if (rc) return rc;
             // one launch: this layer's weight-gradient products, the reduction of the layer above's products and the
             // BatchNorm-backward finish of the layer below (its partial sums were just written)

@@ -88,6 +88,7 @@ struct EdgeFwdArgs {
     int B, V, C, H, mean_agg;
     EdgeSrc src;
     const float* WU; const float* bU;
+    const u32x4* WUs;           // above 64 channels: bf16 planes of WU in fragment order (k_split_weights)
     const float* Ve; const float* Vn; const float* Ux;
     float* e_tmp; float* x_tmp; float* Aout; float* Dout; float* partial;
     const unsigned long long* rng;
@@ -192,6 +193,7 @@ struct EdgeBwdArgs {
     int B, V, C, H, IT, mean_agg;
     float* de;
     const float* e_tmp; const float* WUt;      // edge_feat.U: transposed copy (wide kernels) or as stored (strip kernels)
+    const u32x4* WUs;                          // above 64 channels: bf16 planes of WU^T in fragment order (k_split_weights)
     const float* Vn; const float* Aagg; const float* Dn;
     const float* dx; const float* x_tmp;
     const float* stats;                                   // [4][H] mean_e, rstd_e, mean_x, rstd_x

@@ -1,0 +1,587 @@
+// Edge kernels for hidden sizes above 64 with the H x H products on the bf16 matrix pipe at fp32 accuracy.
+//
+// An fp32 value x is cut into three bf16 pieces x = x1 + x2 + x3, each piece the round-to-nearest bf16 of what the
+// pieces before it left over.  The cut is exact (8 + 8 + 8 significant bits), so
+//     a w = a1 w1 + (a1 w2 + a2 w1) + (a2 w2 + a1 w3 + a3 w1) + (a2 w3 + a3 w2 + a3 w3),
+// and the last group is below 2^-26 |a w|: it is dropped.  Every bf16 x bf16 product is exact in fp32 and the sums
+// are accumulated in fp32 by v_mfma_f32_16x16x32_bf16, so a product formed this way is as accurate as an fp32 FMA
+// chain (measured against a float64 product: 4.3e-7 of the largest output against 5.1e-7 for the fp32 MFMA loop at
+// K = 300).  Six bf16 MFMAs of 16 x 16 x 32 take 96 cycles of the matrix pipe where the fp32 form
+// (v_mfma_f32_16x16x4_f32) needs 8 x 32 = 256 for the same block.
+//
+// Layout.  Activations: a step's rows in LDS as three planes of bf16 (row stride 640 B; the 16-byte chunk c of row r
+// sits at chunk c ^ 2 ((r >> 1) & 3), which makes the 128-bit operand reads of a wavefront conflict-free).
+// Weights: cut once per pass by k_split_weights into fragment order, plane p, column block nb, k block kb, lane:
+// lane (rs, q) finds W[16 nb + rs][32 kb + 8 q .. + 7] as one 16-byte load, a wavefront reads 1 KiB contiguous.
+#pragma once
+#include "kernels_wide.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SROWB = GCN_WIDE_MAX_H * 2;         // bytes per LDS row of one plane (320 bf16)
+constexpr int SNS = 4;                            // 16-row tiles per step of the edge kernels
+constexpr int SPB = 16 * SNS * SROWB;             // bytes per LDS plane
+constexpr int STH = 512;                          // threads per workgroup of the edge kernels: 8 wavefronts, one workgroup per CU
+constexpr int SKA = (GCN_WIDE_MAX_H / 4 + 31) / 32;   // float4 column groups per staging thread
+constexpr int SKB8 = (WNB + 7) / 8;               // column blocks per wavefront
+
+// Thread roles in the edge kernels.  Staging: thread (arow, g0) = (t / 32, t % 32) walks the float4 column groups
+// g0, g0 + 32, ... of row arow of every tile of the step.  Product: wavefront w = t / 64 takes the column blocks
+// w, w + 8, ... against all tiles of the step, lane (rs, q) as everywhere.
+struct SplitIdx {
+    int t, lane, rs, q, w, arow, g0;
+};
+__device__ __forceinline__ SplitIdx split_idx() {
+    SplitIdx x;
+    x.t = threadIdx.x; x.lane = x.t & 63; x.rs = x.lane & 15; x.q = x.lane >> 4; x.w = x.t >> 6;
+    x.arow = x.t >> 5; x.g0 = x.t & 31;
+    return x;
+}
+// x[0] <- x[1] <- ... <- x[SKB8-1] <- x[0]: after SKB8 calls every entry is back in place
+__device__ __forceinline__ void rot8(f32x4 (&x)[SKB8]) {
+    const f32x4 t = x[0];
+#pragma unroll
+    for (int k = 0; k + 1 < SKB8; ++k) x[k] = x[k + 1];
+    x[SKB8 - 1] = t;
+}
+
+__host__ __device__ inline int split_nkb(int H) { return (H + 31) / 32; }
+// bytes of the fragment-ordered planes of one H x H matrix
+__host__ __device__ inline size_t split_weight_bytes(int H) { return (size_t)3 * ((H + 15) / 16) * split_nkb(H) * 64 * 16; }
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// two fp32 values -> three packed bf16 pairs (low half = first value)
+struct Split3 { uint32_t p[3]; };
+__device__ __forceinline__ Split3 split2(float x, float y) {
+    Split3 r;
+    r.p[0] = cvt_pk_bf16(x, y);
+    x -= __builtin_bit_cast(float, r.p[0] << 16); y -= __builtin_bit_cast(float, r.p[0] & 0xffff0000u);
+    r.p[1] = cvt_pk_bf16(x, y);
+    x -= __builtin_bit_cast(float, r.p[1] << 16); y -= __builtin_bit_cast(float, r.p[1] & 0xffff0000u);
+    r.p[2] = cvt_pk_bf16(x, y);
+    return r;
+}
+
+// Up to 64 matrices per launch: dst[m] = fragment-ordered planes of src[m] (transposed != 0: of src[m]^T, i.e. the
+// operand of an "X * W" product).  grid (ceil(NB * NKB / 4), matrices), 256 threads: one fragment per wavefront.
+struct SplitList {
+    const float* src[64];
+    u32x4* dst[64];
+    int transposed;
+};
+__global__ __launch_bounds__(256) void k_split_weights(SplitList sl, int H) {
+    const float* __restrict__ W = sl.src[blockIdx.y];
+    u32x4* __restrict__ Wt = sl.dst[blockIdx.y];
+    const int NB = (H + 15) / 16, NKB = split_nkb(H);
+    const int lane = threadIdx.x & 63, rs = lane & 15, q = lane >> 4;
+    const int frag = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frag >= NB * NKB) return;
+    const int nb = frag / NKB, kb = frag - nb * NKB;
+    const int n = 16 * nb + rs;
+    u32x4 o[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 32 * kb + 8 * q + 2 * e;
+        float x = 0.f, y = 0.f;
+        if (n < H) {
+            if (k < H) x = sl.transposed ? W[(size_t)k * H + n] : W[(size_t)n * H + k];
+            if (k + 1 < H) y = sl.transposed ? W[(size_t)(k + 1) * H + n] : W[(size_t)n * H + k + 1];
+        }
+        const Split3 sp = split2(x, y);
+        o[0][e] = sp.p[0]; o[1][e] = sp.p[1]; o[2][e] = sp.p[2];
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) Wt[((size_t)p * NB * NKB + frag) * 64 + lane] = o[p];
+}
+
+// byte offset of the 16-byte chunk (row, chunk) inside a plane
+__device__ __forceinline__ int split_off(int row, int chunk) { return row * SROWB + ((chunk ^ (2 * ((row >> 1) & 3))) << 4); }
+// columns 4 g .. 4 g + 3 of a row: cut and stored to the three planes (8 bytes each)
+__device__ __forceinline__ void split_put4(unsigned char* planes, int row, int g, const f32x4 v) {
+    const Split3 a = split2(v[0], v[1]), b = split2(v[2], v[3]);
+    unsigned char* p = planes + split_off(row, g >> 1) + 8 * (g & 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(p + k * SPB) = uint2{a.p[k], b.p[k]};
+}
+// the same four columns read back: the three pieces add up to the stored fp32 value exactly
+__device__ __forceinline__ f32x4 split_get4(const unsigned char* planes, int row, int g) {
+    const unsigned char* p = planes + split_off(row, g >> 1) + 8 * (g & 1);
+    uint2 u[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] = *reinterpret_cast<const uint2*>(p + k * SPB);
+    f32x4 v;
+    auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+    auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+    v[0] = (lo(u[0].x) + lo(u[1].x)) + lo(u[2].x);
+    v[1] = (hi(u[0].x) + hi(u[1].x)) + hi(u[2].x);
+    v[2] = (lo(u[0].y) + lo(u[1].y)) + lo(u[2].y);
+    v[3] = (hi(u[0].y) + hi(u[1].y)) + hi(u[2].y);
+    return v;
+}
+__device__ __forceinline__ void split_zero_planes(unsigned char* planes, int t) {
+    for (int e = t * 16; e < 3 * SPB; e += STH * 16) *reinterpret_cast<u32x4*>(planes + e) = u32x4{0u, 0u, 0u, 0u};
+}
+
+// Output columns 16 nb + 4 q .. + 3 of rows 16 s + rs (s < NS) of planes * W^T.  The weight fragments of k block
+// kb + 1 are requested before the MFMAs of k block kb; the small products are added first.
+template <int NS>
+__device__ __forceinline__ void split_gemm_ns(const unsigned char* planes, const u32x4* __restrict__ Wt, int NB, int NKB, int nb,
+                                              int lane, int rs, int q, f32x4 (&o)[SNS]) {
+    f32x4 acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = f4zero();
+    const size_t pstride = (size_t)NB * NKB * 64;
+    const u32x4* wb = Wt + (size_t)nb * NKB * 64 + lane;
+    u32x4 w[3], wn[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w[p] = wb[p * pstride];
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int kn = min(kb + 1, NKB - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wn[p] = wb[p * pstride + (size_t)kn * 64];
+        u32x4 a[NS][3];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[s][p] = *reinterpret_cast<const u32x4*>(planes + p * SPB + split_off(16 * s + rs, 4 * kb + q));
+        __builtin_amdgcn_sched_barrier(0);
+#define GCN_SPLIT_MM(s, pw, pa) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[pw]), __builtin_bit_cast(bf16x8, a[s][pa]), acc[s], 0, 0, 0)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 2, 0); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 2); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 1, 1); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 1, 0); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 1); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 0); }
+#undef GCN_SPLIT_MM
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p] = wn[p];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) o[s] = acc[s];
+}
+// ns (wavefront-uniform) = tiles in use, 1 .. SNS; o[s] for s >= ns is left untouched
+__device__ __forceinline__ void split_gemm_n(const unsigned char* planes, int ns, const u32x4* __restrict__ Wt, int NB, int NKB, int nb,
+                                             int lane, int rs, int q, f32x4 (&o)[SNS]) {
+    if (ns >= 4) split_gemm_ns<4>(planes, Wt, NB, NKB, nb, lane, rs, q, o);
+    else if (ns == 3) split_gemm_ns<3>(planes, Wt, NB, NKB, nb, lane, rs, q, o);
+    else if (ns == 2) split_gemm_ns<2>(planes, Wt, NB, NKB, nb, lane, rs, q, o);
+    else split_gemm_ns<1>(planes, Wt, NB, NKB, nb, lane, rs, q, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge forward (EdgeFwdArgs, a.WUs = planes of edge_feat.U.weight).  Workgroups take contiguous ranges of (b, i, c)
+// units and walk their j tiles SNS at a time (64 rows per step: every weight fragment fetched from L2 feeds 24 MFMAs;
+// at 32 rows per step the product phase ran at the rate the L2s deliver the weight planes, 18 TB/s over the chip).
+// partial layout [gridDim.x][4][H].  Dynamic LDS: 3 SPB bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(STH) void k_edge_fwd_ws(EdgeFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
+    __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
+    __shared__ __attribute__((aligned(16))) float ess[2][GCN_WIDE_MAX_H];      // sums of e_tmp, e_tmp^2 over this workgroup's rows
+    const SplitIdx ix = split_idx();
+    const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB, NKB = split_nkb(H);
+    const EdgeSrc& S = a.src;
+    clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
+    clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
+    clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += STH) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; }
+    split_zero_planes(planes, ix.t);
+    const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
+    const int units = a.B * V * C;
+    const int njt = (V + 15) / 16;
+    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    __syncthreads();
+    ACCF_DECL;
+    for (int u = u0; u < u1; ++u) {
+        const int bi = u / C, c = u - bi * C, b = bi / V;
+        f32x4 num[SKB8], den[SKB8];
+#pragma unroll
+        for (int k = 0; k < SKB8; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
+        for (int jt = 0; jt < njt; jt += SNS) {
+            const int ns = min(SNS, njt - jt);
+            // ---- phase A: rows 16 s + arow of the step; all loads of a row are requested before the first is used
+#pragma unroll
+            for (int s = 0; s < SNS; ++s) {
+                if (s >= ns) break;
+                const int j = (jt + s) * 16 + ix.arow;
+                const bool jok = j < V;
+                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
+                const int lrow = 16 * s + ix.arow;
+                if (S.mode == 1) {
+                    f32x4 pt[SKA], pi[SKA];
+#pragma unroll
+                    for (int k = 0; k < SKA; ++k) {
+                        const int acol = 4 * (ix.g0 + 32 * k);
+                        const size_t off = (jok && acol < H) ? erow * H + acol : 0;
+                        pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
+                    }
+                    const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
+#pragma unroll
+                    for (int k = 0; k < SKA; ++k) {
+                        const int g = ix.g0 + 32 * k, acol = 4 * g;
+                        if (acol < HP) {
+                            f32x4 val = f4zero();
+                            if (jok && acol < H) {
+                                val = bn_relu_res4(pt[k], pi[k], &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol], &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
+                                if (dc.on) val *= drop_mul4(dc, rh, g);
+                                if (S.e_out != nullptr) st4(S.e_out + erow * H + acol, val);
+                            }
+                            split_put4(planes, lrow, g, val);
+                        }
+                    }
+                } else {
+                    const float capv = (S.mode == 2 && jok) ? S.cap[(size_t)bi * V + j] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < SKA; ++k) {
+                        const int g = ix.g0 + 32 * k, acol = 4 * g;
+                        if (acol < HP) {
+                            f32x4 val = f4zero();
+                            if (jok && acol < H) {
+                                const size_t off = erow * H + acol;
+                                if (S.mode == 0) val = ld4(S.e_in + off);
+                                else {
+                                    val = ld4(&cl[CL_WE][acol]) * capv;
+                                    if (S.e_out != nullptr) st4(S.e_out + off, val);
+                                }
+                            }
+                            split_put4(planes, lrow, g, val);
+                        }
+                    }
+                }
+            }
+            ACCF(0);
+            __syncthreads();
+            ACCF(1);
+            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
+#pragma unroll 1
+                for (int kk = 0; kk < SKB8; ++kk) {
+                    constexpr int k = 0;
+                    const int nb = ix.w + 8 * kk;
+                    if (nb < NB) {
+                        const int bcol = 16 * nb + 4 * ix.q;
+                        // epilogue operands are requested before the product so that their latency hides under it
+                        const bool cok = bcol < H;
+                        f32x4 vej[SNS], vnj2[SNS];
+                        const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
+#pragma unroll
+                        for (int s = 0; s < SNS; ++s) {
+                            const int j = (jt + s) * 16 + ix.rs;
+                            const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
+                            vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
+                        }
+                        f32x4 et2[SNS];
+                        split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, et2);
+                        ACCF(2);
+                        f32x4 t1 = f4zero(), t2 = f4zero();
+                        if (cok) {
+#pragma unroll
+                            for (int s = 0; s < SNS; ++s) {
+                                const int j = (jt + s) * 16 + ix.rs;
+                                if (s < ns && j < V) {
+                                    const size_t erow = ((size_t)bi * V + j) * C + c;
+                                    const f32x4 et = et2[s] + base + vej[s];
+                                    const f32x4 vnj = vnj2[s];
+                                    st4(a.e_tmp + erow * H + bcol, et);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float g = sigmoidf_(et[r]);
+                                        num[k][r] += g * vnj[r];
+                                        den[k][r] += g;
+                                        t1[r] += et[r];
+                                        t2[r] += et[r] * et[r];
+                                    }
+                                }
+                            }
+                        }
+                        wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
+                        ACCF(3);
+                    }
+                    rot8(num); rot8(den);
+                }
+            }
+            ACCF(4);
+            __syncthreads();
+            ACCF(5);
+        }
+        // ---- unit end
+#pragma unroll
+        for (int k = 0; k < SKB8; ++k) {
+            const int nb = ix.w + 8 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                const f32x4 nm = red16x4(num[k]), dn = red16x4(den[k]);
+                if (ix.rs == 0 && bcol < H) {
+                    f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
+                    if (a.mean_agg) {
+                        D = dn + 1e-20f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) A[r] = nm[r] * __builtin_amdgcn_rcpf(D[r]);
+                    }
+                    const f32x4 xt = ld4(a.Ux + (size_t)u * H + bcol) + A;
+                    st4(a.x_tmp + (size_t)u * H + bcol, xt);
+                    st4(a.Aout + (size_t)u * H + bcol, A);
+                    st4(a.Dout + (size_t)u * H + bcol, D);
+                    // this lane is the only one that ever touches these four columns of pxs
+                    st4(&pxs[0][bcol], ld4(&pxs[0][bcol]) + xt);
+                    st4(&pxs[1][bcol], ld4(&pxs[1][bcol]) + xt * xt);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SKB8; ++k) {
+        const int nb = ix.w + 8 * k;
+        if (nb < NB) {
+            const int bcol = 16 * nb + 4 * ix.q;
+            if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+                float* p = a.partial + (size_t)blockIdx.x * 4 * H;
+                st4(p + bcol, ld4(&ess[0][bcol])); st4(p + H + bcol, ld4(&ess[1][bcol]));
+                st4(p + 2 * H + bcol, ld4(&pxs[0][bcol])); st4(p + 3 * H + bcol, ld4(&pxs[1][bcol]));
+            }
+        }
+    }
+    ACCF(6);
+    ACCF_END(ix.w, ix.lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge backward (EdgeBwdArgs, a.WUs = planes of edge_feat.U.weight^T).  Contiguous ranges of (b, it, jt, c) units, c
+// fastest; a unit walks its rows i SNS at a time (LDS rows 16 s .. 16 s + 15: the 16 columns j of row i + s), so the
+// column partial sums of a staging thread cover all of them.  The residual-branch term dpre = de * dropout mask is
+// re-read in the product phase by the thread that overwrites it.  Dynamic LDS: 3 SPB bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(STH) void k_edge_bwd_ws(EdgeBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
+    __shared__ __attribute__((aligned(16))) float cc[6][GCN_WIDE_MAX_H];    // constants of the edge BatchNorm backward
+    __shared__ __attribute__((aligned(16))) float qa[SNS][2][GCN_WIDE_MAX_H]; // per row of the step: qi, aggregate A
+    __shared__ __attribute__((aligned(16))) float nss[2][GCN_WIDE_MAX_H];     // BN-backward sums of the layer below over this workgroup's rows
+    const SplitIdx ix = split_idx();
+    const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB, NKB = split_nkb(H);
+    const bool do_next = a.next.tmp != nullptr;
+    const bool mean_agg = a.mean_agg != 0;
+    clds_fill(cc[0], a.stats, H, HP); clds_fill(cc[1], a.stats + H, H, HP);
+    clds_fill(cc[2], a.gamma_e, H, HP); clds_fill(cc[3], a.beta_e, H, HP);
+    clds_fill(cc[4], a.bstats_e, H, HP); clds_fill(cc[5], a.bstats_e + H, H, HP);
+    const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    split_zero_planes(planes, ix.t);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += STH) (&nss[0][0])[k] = 0.f;
+    const int njt = (V + 15) / 16;
+    const int nit = (V + IT - 1) / IT;
+    const int units = a.B * nit * njt * C;
+    const size_t Rn = (size_t)a.B * V * C;
+    // balanced ranges: every workgroup gets floor or ceil of units / gridDim.x
+    const int u0 = (int)((long long)blockIdx.x * units / (int)gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * units / (int)gridDim.x);
+    __syncthreads();
+    ACCB_DECL;
+    for (int u = u0; u < u1; ++u) {
+        int tt = u;
+        const int c = tt % C; tt /= C;
+        const int jt = tt % njt; tt /= njt;
+        const int it = tt % nit;
+        const int b = tt / nit;
+        const int ja = jt * 16 + ix.arow;
+        const bool jaok = ja < V;
+        const size_t nrow_ja = (size_t)(b * V + min(ja, V - 1)) * C + c;
+        f32x4 cve[SKA], cvn[SKA];
+#pragma unroll
+        for (int k = 0; k < SKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
+        const int i_end = min(V, (it + 1) * IT);
+        for (int i = it * IT; i < i_end; i += SNS) {
+            const int ns = min(SNS, i_end - i);
+            // Requested before anything else of the step: the Vn row of column j (it serves every row i of the step) and
+            // the two streams of the first row; the streams of the later rows follow when their turn comes.
+            f32x4 vnv[SKA], dnv[SKA], tpv[SKA];
+            auto load_streams = [&](int s) {
+                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
+#pragma unroll
+                for (int k = 0; k < SKA; ++k) {
+                    const int acol = 4 * (ix.g0 + 32 * k);
+                    const size_t off = (jaok && acol < H) ? erow * H + acol : 0;
+                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < SKA; ++k) {
+                const int acol = 4 * (ix.g0 + 32 * k);
+                vnv[k] = ld4(a.Vn + ((jaok && acol < H) ? nrow_ja * H + acol : 0));
+            }
+            load_streams(0);
+            // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
+            if (ix.t < SNS * (HP / 4)) {
+                const int s = ix.t / (HP / 4), g = ix.t - s * (HP / 4), acol = 4 * g;
+                f32x4 qv = f4zero(), ai = f4zero();
+                if (s < ns && acol < H) {
+                    const size_t nrow_i = (size_t)(b * V + i + s) * C + c;
+                    const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
+                    f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
+                    f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (dcx.on) dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), g);
+                    const f32x4 xmu = ld4(a.stats + 2 * H + acol), xrs = ld4(a.stats + 3 * H + acol), xga = ld4(a.gamma_x + acol);
+                    const f32x4 xbe = ld4(a.beta_x + acol), xm1 = ld4(a.bstats_x + acol), xm2 = ld4(a.bstats_x + H + acol);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xhx = (xt[r] - xmu[r]) * xrs[r];
+                        const float bnx = xhx * xga[r] + xbe[r];
+                        const float dxd = dxn[r] * dmx[r];
+                        const float dbnx = bnx > 0.f ? dxd : 0.f;
+                        const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
+                        qv[r] = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[r]) : dxt;
+                    }
+                }
+                st4(&qa[s][0][acol], qv);
+                st4(&qa[s][1][acol], ai);
+            }
+            ACCB(0);
+            __syncthreads();
+            ACCB(1);
+            // ---- phase A
+#pragma unroll
+            for (int s = 0; s < SNS; ++s) {
+                if (s >= ns) break;
+                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
+                const int lrow = 16 * s + ix.arow;
+                if (s > 0) load_streams(s);
+                const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
+#pragma unroll
+                for (int k = 0; k < SKA; ++k) {
+                    const int g = ix.g0 + 32 * k;
+                    const int acol = 4 * g;
+                    if (acol < HP) {
+                        f32x4 det = f4zero();
+                        if (jaok && acol < H) {
+                            const f32x4 qv = ld4(&qa[s][0][acol]), ai = ld4(&qa[s][1][acol]);
+                            const f32x4 dn = dnv[k], tp = tpv[k];
+                            const f32x4 vnj = vnv[k];
+                            f32x4 dme = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (dce.on) dme = drop_mul4(dce, rhe, g);
+                            const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
+                            const f32x4 ebe = ld4(&cc[3][acol]), em1 = ld4(&cc[4][acol]), em2 = ld4(&cc[5][acol]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float qi = qv[r];
+                                const float x = tp[r];
+                                const float xh = (x - emu[r]) * ers[r];
+                                const float bn = xh * ega[r] + ebe[r];
+                                const float d = dn[r] * dme[r];
+                                const float dbn = bn > 0.f ? d : 0.f;
+                                const float gt = sigmoidf_(x);
+                                const float v = ega[r] * ers[r] * (dbn - em1[r] - xh * em2[r]) + qi * (vnj[r] - ai[r]) * gt * (1.f - gt);
+                                det[r] = v;
+                                cve[k][r] += v;
+                                cvn[k][r] += qi * gt;
+                            }
+                            st4(a.det_out + erow * H + acol, det);
+                        }
+                        split_put4(planes, lrow, g, det);
+                    }
+                }
+            }
+            ACCB(2);
+            __syncthreads();
+            ACCB(3);
+            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
+                const int jb = jt * 16 + ix.rs;
+                const bool jbok = jb < V;
+                const size_t erow_b0 = ((size_t)(b * V + i) * V + min(jb, V - 1)) * C + c;
+                const size_t nrow_i0 = (size_t)(b * V + i) * C + c;
+#pragma unroll 1
+                for (int kk = 0; kk < SKB8; ++kk) {
+                    const int nb = ix.w + 8 * kk;
+                    if (nb < NB) {
+                        const int bcol = 16 * nb + 4 * ix.q;
+                        const bool valid_b = jbok && bcol < H;
+                        // this thread's elements of de (read here, overwritten below) and of the next layer's pre-BN tensor
+                        f32x4 dold[SNS], ntp[SNS];
+#pragma unroll
+                        for (int s = 0; s < SNS; ++s) {
+                            const size_t off = (valid_b && s < ns) ? (erow_b0 + (size_t)s * V * C) * H + bcol : 0;
+                            dold[s] = ld4(a.de + off);
+                            ntp[s] = do_next ? ld4(a.next.tmp + off) : f4zero();
+                        }
+                        f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
+                        if (do_next) {
+                            const int cb = bcol < H ? bcol : 0;
+                            nmu = ld4(a.next.mean + cb); nrs = ld4(a.next.rstd + cb); nga = ld4(a.next.gamma + cb); nbe = ld4(a.next.beta + cb);
+                        }
+                        f32x4 o2[SNS];
+                        split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, o2);
+                        ACCB(4);
+                        f32x4 t1 = f4zero(), t2 = f4zero();
+#pragma unroll
+                        for (int s = 0; s < SNS; ++s) {
+                            if (s >= ns) break;
+                            const size_t erow_b = erow_b0 + (size_t)s * V * C;
+                            f32x4 rsum = split_get4(planes, 16 * s + ix.rs, bcol >> 2);
+                            if (valid_b) {
+                                f32x4 dpre = dold[s];
+                                if (dce.on) dpre *= drop_mul4(dce, drop_rowhash(dce, (uint32_t)erow_b), bcol >> 2);
+                                const f32x4 din = o2[s] + dpre;
+                                st4(a.de + erow_b * H + bcol, din);
+                                if (do_next) {
+                                    f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                                    if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)erow_b), bcol >> 2);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
+                                        const float bn = xh * nga[r] + nbe[r];
+                                        const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
+                                        t1[r] += d;
+                                        t2[r] += d * xh;
+                                    }
+                                }
+                            }
+                            rsum = red16x4(rsum);
+                            if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i0 + (size_t)s * C) * H + bcol, rsum);
+                        }
+                        if (do_next) wide_acc_cols(nss, bcol, ix.rs == 0 && bcol < H, t1, t2);
+                        ACCB(5);
+                    }
+                }
+            }
+            ACCB(6);
+            __syncthreads();
+            ACCB(7);
+        }
+        if (jaok) {
+#pragma unroll
+            for (int k = 0; k < SKA; ++k) {
+                const int acol = 4 * (ix.g0 + 32 * k);
+                if (acol < H) {
+                    st4(a.colVe + ((size_t)it * Rn + nrow_ja) * H + acol, cve[k]);
+                    st4(a.colVn + ((size_t)it * Rn + nrow_ja) * H + acol, cvn[k]);
+                }
+            }
+        }
+    }
+    if (do_next) {
+#pragma unroll
+        for (int k = 0; k < SKB8; ++k) {
+            const int nb = ix.w + 8 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nss[0][bcol]));
+                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nss[1][bcol]));
+                }
+            }
+        }
+    }
+    ACCB_END(ix.w, ix.lane);
+}
