@@ -408,7 +408,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         if constexpr (MT == 0) {
             a.WUs = W.wsplit;
             if (int rc = reserve_split_lds(k_edge_fwd_ws, "k_edge_fwd_ws")) return rc;
-            GCN_LAUNCH_TIMED_LDS("k_edge_fwd_ws", k_edge_fwd_ws, W.nblk, STH, 3 * SPB, a);
+            GCN_LAUNCH_TIMED_LDS("k_edge_fwd_ws", k_edge_fwd_ws, W.nblk, SFT, 3 * SPB, a);
         } else {
             bool launched = false;
             if constexpr (MT == 2 || MT == 4) {
@@ -872,8 +872,8 @@ extern "C" int gcn_phase_trace_read(unsigned long long* host_out /* [512] */) {
 }
 #endif
 #ifdef GCN_PHASE_ACC
-extern "C" int gcn_phase_acc_read(unsigned long long* host_out /* [1024][4][8] */) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 1024 * 4 * 8) == hipSuccess ? 0 : -1;
+extern "C" int gcn_phase_acc_read(unsigned long long* host_out /* [1024][12][8] */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_acc), sizeof(unsigned long long) * 1024 * 12 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 const char* gcn_last_error(void) { return g_err; }

@@ -262,9 +262,10 @@ __device__ __forceinline__ void wide_acc_cols(float (*acc)[GCN_WIDE_MAX_H], int 
 }
 
 // Phase accounting (measurement builds, -DGCN_PHASE_ACC=1 forward / =2 backward edge kernel): every wavefront adds up
-// the shader-clock cycles it spends in each phase of its steps over the whole launch; g_phase_acc[workgroup][wavefront][slot].
+// the shader-clock cycles it spends in each phase of its steps over the whole launch; g_phase_acc[workgroup][wavefront][slot]
+// (up to twelve wavefronts per workgroup).
 #ifdef GCN_PHASE_ACC
-__device__ unsigned long long g_phase_acc[1024][4][8];
+__device__ unsigned long long g_phase_acc[1024][12][8];
 #define GCN_ACC_DECL unsigned long long pa_t_ = clock64(), pa_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define GCN_ACC(slot) do { const unsigned long long n_ = clock64(); pa_[slot] += n_ - pa_t_; pa_t_ = n_; } while (0)
 #define GCN_ACC_END(w, lane) do { if ((lane) == 0 && blockIdx.x < 1024) for (int k_ = 0; k_ < 8; ++k_) g_phase_acc[blockIdx.x][w][k_] = pa_[k_]; } while (0)

@@ -182,149 +182,190 @@ __device__ __forceinline__ void split_gemm_n(const unsigned char* planes, int ns
 
 // ------------------------------------------------------------------------------------------------
 // Edge forward (EdgeFwdArgs, a.WUs = planes of edge_feat.U.weight).  Workgroups take contiguous ranges of (b, i, c)
-// units and walk their j tiles SNS at a time (64 rows per step: every weight fragment fetched from L2 feeds 24 MFMAs;
-// at 32 rows per step the product phase ran at the rate the L2s deliver the weight planes, 18 TB/s over the chip).
+// units and walk their j tiles SNS at a time: 64 rows per step, so that every weight fragment fetched from L2 feeds 24
+// MFMAs (at 32 rows per step the product phase ran at the rate the L2s deliver the weight planes, 18 TB/s over the
+// chip).  One 768-thread workgroup per CU, two roles:
+//   wavefronts 0..7 (two per SIMD, which hide each other's waits for weight fragments and LDS operands) multiply:
+//     column blocks w, w + 8, ... of the step's rows, epilogue, sums;
+//   wavefronts 8..11 (one per SIMD) stage: while step n is multiplied they fetch the rows of step n + 1 from memory,
+//     form the layer input (fused BatchNorm apply / embedding), write it out and keep it in registers (80 per lane);
+//     once step n's product is done they cut the values into the bf16 planes in LDS.
+// A wavefront's vector-memory operations retire in issue order, so a wavefront that waits for weight fragments from
+// L2 every few hundred cycles cannot also have rows from HBM in flight; split by role, the HBM stream runs under the
+// whole product phase (with every wavefront doing both in turn, the chip alternated between an HBM-bound phase with
+// the matrix pipe idle and a product phase with HBM idle: 39 % + 42 % of the kernel).
 // partial layout [gridDim.x][4][H].  Dynamic LDS: 3 SPB bytes.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(STH) void k_edge_fwd_ws(EdgeFwdArgs a) {
+constexpr int SFT = 768;        // threads of the forward kernel: 512 multiplying + 256 staging
+__global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
     __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
     __shared__ __attribute__((aligned(16))) float ess[2][GCN_WIDE_MAX_H];      // sums of e_tmp, e_tmp^2 over this workgroup's rows
-    const SplitIdx ix = split_idx();
+    __shared__ __attribute__((aligned(16))) float agg[2][GCN_WIDE_MAX_H];      // gated sums of the unit in progress: sum_j g Vn_j, sum_j g
     const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB, NKB = split_nkb(H);
     const EdgeSrc& S = a.src;
     clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
-    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += STH) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; }
-    split_zero_planes(planes, ix.t);
-    const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
+    for (int k = threadIdx.x; k < 2 * GCN_WIDE_MAX_H; k += SFT) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; (&agg[0][0])[k] = 0.f; }
+    for (int e = threadIdx.x * 16; e < 3 * SPB; e += SFT * 16) *reinterpret_cast<u32x4*>(planes + e) = u32x4{0u, 0u, 0u, 0u};
     const int units = a.B * V * C;
     const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
     const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
     __syncthreads();
-    ACCF_DECL;
-    for (int u = u0; u < u1; ++u) {
-        const int bi = u / C, c = u - bi * C, b = bi / V;
-        f32x4 num[SKB8], den[SKB8];
-#pragma unroll
-        for (int k = 0; k < SKB8; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
-        for (int jt = 0; jt < njt; jt += SNS) {
-            const int ns = min(SNS, njt - jt);
-            // ---- phase A: rows 16 s + arow of the step; all loads of a row are requested before the first is used
+    if (threadIdx.x >= STH) {
+        // ---------------------------------------------------------------- staging wavefronts
+        const int pt = threadIdx.x - STH, arow = pt >> 4, g0 = pt & 15;
+        const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
+        f32x4 val[SNS][WKA];
+        // rows 16 s + arow of the step (u, jt): layer input -> val (zeros outside the problem), written to e_out
+        auto produce = [&](int u, int jt, int ns) {
+            const int bi = u / C, c = u - bi * C;
 #pragma unroll
             for (int s = 0; s < SNS; ++s) {
-                if (s >= ns) break;
-                const int j = (jt + s) * 16 + ix.arow;
+#pragma unroll
+                for (int k = 0; k < WKA; ++k) val[s][k] = f4zero();
+                if (s >= ns) continue;
+                const int j = (jt + s) * 16 + arow;
                 const bool jok = j < V;
                 const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
-                const int lrow = 16 * s + ix.arow;
                 if (S.mode == 1) {
-                    f32x4 pt[SKA], pi[SKA];
+                    f32x4 tp[WKA], ti[WKA];
 #pragma unroll
-                    for (int k = 0; k < SKA; ++k) {
-                        const int acol = 4 * (ix.g0 + 32 * k);
+                    for (int k = 0; k < WKA; ++k) {
+                        const int acol = 4 * (g0 + 16 * k);
                         const size_t off = (jok && acol < H) ? erow * H + acol : 0;
-                        pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
+                        tp[k] = ld4(S.prev_tmp + off); ti[k] = ld4(S.prev_in + off);
                     }
                     const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
 #pragma unroll
-                    for (int k = 0; k < SKA; ++k) {
-                        const int g = ix.g0 + 32 * k, acol = 4 * g;
-                        if (acol < HP) {
-                            f32x4 val = f4zero();
-                            if (jok && acol < H) {
-                                val = bn_relu_res4(pt[k], pi[k], &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol], &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
-                                if (dc.on) val *= drop_mul4(dc, rh, g);
-                                if (S.e_out != nullptr) st4(S.e_out + erow * H + acol, val);
-                            }
-                            split_put4(planes, lrow, g, val);
+                    for (int k = 0; k < WKA; ++k) {
+                        const int g = g0 + 16 * k, acol = 4 * g;
+                        if (jok && acol < H) {
+                            f32x4 v = bn_relu_res4(tp[k], ti[k], &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol], &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
+                            if (dc.on) v *= drop_mul4(dc, rh, g);
+                            if (S.e_out != nullptr) st4(S.e_out + erow * H + acol, v);
+                            val[s][k] = v;
                         }
                     }
                 } else {
                     const float capv = (S.mode == 2 && jok) ? S.cap[(size_t)bi * V + j] : 0.f;
 #pragma unroll
-                    for (int k = 0; k < SKA; ++k) {
-                        const int g = ix.g0 + 32 * k, acol = 4 * g;
-                        if (acol < HP) {
-                            f32x4 val = f4zero();
-                            if (jok && acol < H) {
-                                const size_t off = erow * H + acol;
-                                if (S.mode == 0) val = ld4(S.e_in + off);
-                                else {
-                                    val = ld4(&cl[CL_WE][acol]) * capv;
-                                    if (S.e_out != nullptr) st4(S.e_out + off, val);
-                                }
+                    for (int k = 0; k < WKA; ++k) {
+                        const int acol = 4 * (g0 + 16 * k);
+                        if (jok && acol < H) {
+                            const size_t off = erow * H + acol;
+                            f32x4 v;
+                            if (S.mode == 0) v = ld4(S.e_in + off);
+                            else {
+                                v = ld4(&cl[CL_WE][acol]) * capv;
+                                if (S.e_out != nullptr) st4(S.e_out + off, v);
                             }
-                            split_put4(planes, lrow, g, val);
+                            val[s][k] = v;
                         }
                     }
                 }
             }
+        };
+        if (u0 < u1) produce(u0, 0, min(SNS, njt));
+        ACCF_DECL;
+        for (int u = u0; u < u1; ++u) {
+            for (int jt = 0; jt < njt; jt += SNS) {
+                const int ns = min(SNS, njt - jt);
+#pragma unroll
+                for (int s = 0; s < SNS; ++s) {
+                    if (s >= ns) break;
+#pragma unroll
+                    for (int k = 0; k < WKA; ++k) {
+                        const int g = g0 + 16 * k;
+                        if (4 * g < HP) split_put4(planes, 16 * s + arow, g, val[s][k]);
+                    }
+                }
+                ACCF(0);
+                __syncthreads();                    // the planes of this step are complete
+                ACCF(1);
+                int nu = u, nj = jt + SNS;
+                if (nj >= njt) { nu = u + 1; nj = 0; }
+                if (nu < u1) produce(nu, nj, min(SNS, njt - nj));
+                ACCF(2);
+                __syncthreads();                    // the product of this step is done: the planes may be overwritten
+                ACCF(5);
+            }
+        }
+        ACCF_END(threadIdx.x >> 6, threadIdx.x & 63);
+        return;
+    }
+    // -------------------------------------------------------------------- multiplying wavefronts
+    const SplitIdx ix = split_idx();
+    ACCF_DECL;
+    for (int u = u0; u < u1; ++u) {
+        const int bi = u / C, c = u - bi * C, b = bi / V;
+        for (int jt = 0; jt < njt; jt += SNS) {
+            const int ns = min(SNS, njt - jt);
             ACCF(0);
             __syncthreads();
             ACCF(1);
-            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
 #pragma unroll 1
-                for (int kk = 0; kk < SKB8; ++kk) {
-                    constexpr int k = 0;
-                    const int nb = ix.w + 8 * kk;
-                    if (nb < NB) {
-                        const int bcol = 16 * nb + 4 * ix.q;
-                        // epilogue operands are requested before the product so that their latency hides under it
-                        const bool cok = bcol < H;
-                        f32x4 vej[SNS], vnj2[SNS];
-                        const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
+            for (int kk = 0; kk < SKB8; ++kk) {
+                const int nb = ix.w + 8 * kk;
+                if (nb < NB) {
+                    const int bcol = 16 * nb + 4 * ix.q;
+                    // epilogue operands are requested before the product so that their latency hides under it
+                    const bool cok = bcol < H;
+                    f32x4 vej[SNS], vnj2[SNS];
+                    const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
+#pragma unroll
+                    for (int s = 0; s < SNS; ++s) {
+                        const int j = (jt + s) * 16 + ix.rs;
+                        const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
+                        vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
+                    }
+                    f32x4 et2[SNS];
+                    split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, et2);
+                    ACCF(2);
+                    f32x4 t1 = f4zero(), t2 = f4zero(), nm = f4zero(), dn = f4zero();
+                    if (cok) {
 #pragma unroll
                         for (int s = 0; s < SNS; ++s) {
                             const int j = (jt + s) * 16 + ix.rs;
-                            const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
-                            vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
-                        }
-                        f32x4 et2[SNS];
-                        split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, et2);
-                        ACCF(2);
-                        f32x4 t1 = f4zero(), t2 = f4zero();
-                        if (cok) {
+                            if (s < ns && j < V) {
+                                const size_t erow = ((size_t)bi * V + j) * C + c;
+                                const f32x4 et = et2[s] + base + vej[s];
+                                const f32x4 vnj = vnj2[s];
+                                st4(a.e_tmp + erow * H + bcol, et);
 #pragma unroll
-                            for (int s = 0; s < SNS; ++s) {
-                                const int j = (jt + s) * 16 + ix.rs;
-                                if (s < ns && j < V) {
-                                    const size_t erow = ((size_t)bi * V + j) * C + c;
-                                    const f32x4 et = et2[s] + base + vej[s];
-                                    const f32x4 vnj = vnj2[s];
-                                    st4(a.e_tmp + erow * H + bcol, et);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const float g = sigmoidf_(et[r]);
-                                        num[k][r] += g * vnj[r];
-                                        den[k][r] += g;
-                                        t1[r] += et[r];
-                                        t2[r] += et[r] * et[r];
-                                    }
+                                for (int r = 0; r < 4; ++r) {
+                                    const float g = sigmoidf_(et[r]);
+                                    nm[r] += g * vnj[r];
+                                    dn[r] += g;
+                                    t1[r] += et[r];
+                                    t2[r] += et[r] * et[r];
                                 }
                             }
                         }
-                        wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
-                        ACCF(3);
                     }
-                    rot8(num); rot8(den);
+                    // sums over the step's rows, added by the lane that owns the four columns (same lane, same
+                    // address every time: fixed order, no atomics)
+                    wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
+                    wide_acc_cols(agg, bcol, ix.rs == 0 && cok, nm, dn);
+                    ACCF(3);
                 }
             }
             ACCF(4);
             __syncthreads();
             ACCF(5);
         }
-        // ---- unit end
+        // ---- unit end: the lane that accumulated these columns
 #pragma unroll
         for (int k = 0; k < SKB8; ++k) {
             const int nb = ix.w + 8 * k;
             if (nb < NB) {
                 const int bcol = 16 * nb + 4 * ix.q;
-                const f32x4 nm = red16x4(num[k]), dn = red16x4(den[k]);
                 if (ix.rs == 0 && bcol < H) {
+                    const f32x4 nm = ld4(&agg[0][bcol]), dn = ld4(&agg[1][bcol]);
+                    st4(&agg[0][bcol], f4zero()); st4(&agg[1][bcol], f4zero());
                     f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
                     if (a.mean_agg) {
                         D = dn + 1e-20f;

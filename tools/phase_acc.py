@@ -30,16 +30,20 @@ for _ in range(2):
     step.step()
 torch.cuda.synchronize()
 lib = L.load()
-buf = (ctypes.c_ulonglong * (1024 * 4 * 8))()
+buf = (ctypes.c_ulonglong * (1024 * 12 * 8))()
 lib.gcn_phase_acc_read.argtypes = [ctypes.c_void_p]
 assert lib.gcn_phase_acc_read(buf) == 0
-t = np.array(buf[:], dtype=np.float64).reshape(1024, 4, 8)
+t = np.array(buf[:], dtype=np.float64).reshape(1024, 12, 8)
 used = t.sum(axis=(1, 2)) > 0
 t = t[used]
-names = (["stage", "barrier", "product", "epilogue", "loop end", "barrier2", "tail", "(weight wait inside product, -DGCN_ACC_GEMM)"] if which == "fwd" else
+# forward kernel: wavefronts 0..7 multiply (slots: wait for the planes, product, epilogue, loop end, wait for the stagers),
+# wavefronts 8..11 stage (slots: cut into planes, wait, fetch + form the next step's rows, wait for the product)
+names = (["cut / -", "wait planes", "product / fetch", "epilogue", "loop end", "wait other role", "tail", "-"] if which == "fwd" else
          ["node side", "barrier", "stage", "barrier", "product", "epilogue", "loop end", "barrier3"])
 tot = t.sum(axis=2)
 print(f"{int(used.sum())} workgroups; cycles per wavefront: mean {tot.mean():.0f}, min {tot.min():.0f}, max {tot.max():.0f}")
-for w in range(4):
+for w in range(12):
+    if tot[:, w].sum() == 0:
+        continue
     print(f"wavefront {w}: " + "  ".join(f"{n} {t[:, w, k].mean() / tot[:, w].mean() * 100:5.1f}%" for k, n in enumerate(names) if n != "-"))
 print("all       : " + "  ".join(f"{n} {t[:, :, k].sum() / tot.sum() * 100:5.1f}%" for k, n in enumerate(names) if n != "-"))
