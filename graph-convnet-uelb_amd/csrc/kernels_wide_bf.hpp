@@ -127,7 +127,8 @@ __device__ __forceinline__ void split_zero_planes(unsigned char* planes, int t) 
 }
 
 // Output columns 16 nb + 4 q .. + 3 of rows 16 s + rs (s < NS) of planes * W^T.  The weight fragments of k block
-// kb + 1 are requested before the MFMAs of k block kb; the small products are added first.
+// kb + 1 are requested before the MFMAs of k block kb; the LDS operands of a tile (three 128-bit reads) are requested
+// while the six MFMAs of the tile before it run (two register sets of three); the small products are added first.
 template <int NS>
 __device__ __forceinline__ void split_gemm_ns(const unsigned char* planes, const u32x4* __restrict__ Wt, int NB, int NKB, int nb,
                                               int lane, int rs, int q, f32x4 (&o)[SNS]) {
@@ -139,34 +140,37 @@ __device__ __forceinline__ void split_gemm_ns(const unsigned char* planes, const
     u32x4 w[3], wn[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) w[p] = wb[p * pstride];
-    for (int kb = 0; kb < NKB; ++kb) {
-        const int kn = min(kb + 1, NKB - 1);
+    auto read_tile = [&](u32x4 (&a)[3], int s, int kb) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wn[p] = wb[p * pstride + (size_t)kn * 64];
-        u32x4 a[NS][3];
+        for (int p = 0; p < 3; ++p)
+            a[p] = *reinterpret_cast<const u32x4*>(planes + p * SPB + split_off(16 * s + rs, 4 * min(kb, NKB - 1) + q));
+    };
+    u32x4 a[2][3];
+    read_tile(a[0], 0, 0);
+    // two k blocks per trip so that the register set a tile sits in is known at compile time
+    for (int kb0 = 0; kb0 < NKB; kb0 += 2) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int d = 0; d < 2; ++d) {
+            const int kb = kb0 + d;
+            if (kb < NKB) {
+                const int kn = min(kb + 1, NKB - 1);
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[s][p] = *reinterpret_cast<const u32x4*>(planes + p * SPB + split_off(16 * s + rs, 4 * kb + q));
-        __builtin_amdgcn_sched_barrier(0);
-#define GCN_SPLIT_MM(s, pw, pa) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[pw]), __builtin_bit_cast(bf16x8, a[s][pa]), acc[s], 0, 0, 0)
+                for (int p = 0; p < 3; ++p) wn[p] = wb[p * pstride + (size_t)kn * 64];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 2, 0); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 2); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 1, 1); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 1, 0); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 1); }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) { GCN_SPLIT_MM(s, 0, 0); }
+                for (int s = 0; s < NS; ++s) {
+                    const int cur = (NS * d + s) & 1;
+                    if (s + 1 < NS) read_tile(a[cur ^ 1], s + 1, kb);
+                    else read_tile(a[cur ^ 1], 0, kb + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#define GCN_SPLIT_MM(pw, pa) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[pw]), __builtin_bit_cast(bf16x8, a[cur][pa]), acc[s], 0, 0, 0)
+                    GCN_SPLIT_MM(2, 0); GCN_SPLIT_MM(0, 2); GCN_SPLIT_MM(1, 1); GCN_SPLIT_MM(1, 0); GCN_SPLIT_MM(0, 1); GCN_SPLIT_MM(0, 0);
 #undef GCN_SPLIT_MM
-        __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = wn[p];
+                for (int p = 0; p < 3; ++p) w[p] = wn[p];
+            }
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) o[s] = acc[s];
@@ -181,10 +185,12 @@ __device__ __forceinline__ void split_gemm_n(const unsigned char* planes, int ns
 }
 
 // ------------------------------------------------------------------------------------------------
-// Edge forward (EdgeFwdArgs, a.WUs = planes of edge_feat.U.weight).  Workgroups take contiguous ranges of (b, i, c)
-// units and walk their j tiles SNS at a time: 64 rows per step, so that every weight fragment fetched from L2 feeds 24
-// MFMAs (at 32 rows per step the product phase ran at the rate the L2s deliver the weight planes, 18 TB/s over the
-// chip).  One 768-thread workgroup per CU, two roles:
+// Edge forward (EdgeFwdArgs, a.WUs = planes of edge_feat.U.weight).  A workgroup takes a contiguous range of (b, i, c)
+// units; the rows j of its units, one unit after the other, form one sequence that is walked 64 rows (SNS tiles) per
+// step, so that every weight fragment fetched from L2 feeds 24 MFMAs (at 32 rows per step the product phase ran at the
+// rate the L2s deliver the weight planes, 18 TB/s over the chip).  From V = 64 on a step runs on across the end of a unit
+// (it then holds rows of two units: no ragged last tile per unit, V = 100 takes 1.56 steps per unit instead of 2);
+// below that a step ends with its unit.  One 768-thread workgroup per CU, two roles:
 //   wavefronts 0..7 (two per SIMD, which hide each other's waits for weight fragments and LDS operands) multiply:
 //     column blocks w, w + 8, ... of the step's rows, epilogue, sums;
 //   wavefronts 8..11 (one per SIMD) stage: while step n is multiplied they fetch the rows of step n + 1 from memory,
@@ -197,47 +203,66 @@ __device__ __forceinline__ void split_gemm_n(const unsigned char* planes, int ns
 // partial layout [gridDim.x][4][H].  Dynamic LDS: 3 SPB bytes.
 // ------------------------------------------------------------------------------------------------
 constexpr int SFT = 768;        // threads of the forward kernel: 512 multiplying + 256 staging
+// A step of the row sequence: it starts at row j0 of unit u and holds n rows (rows past the end of unit u belong to
+// unit u + 1: at most one boundary per step).
+struct FwdStep {
+    int u, j0, n;
+};
+__device__ __forceinline__ FwdStep fwd_step_at(int u, int j0, int u1, int V, bool span) {
+    FwdStep st;
+    st.u = u; st.j0 = j0;
+    const long long avail = span ? (long long)(u1 - u) * V - j0 : (long long)(V - j0);
+    st.n = (int)(avail < 16 * SNS ? avail : 16 * SNS);
+    return st;
+}
+__device__ __forceinline__ void fwd_step_next(int& u, int& j0, int n, int V) {
+    j0 += n;
+    if (j0 >= V) { j0 -= V; ++u; }
+}
 __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
     __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
     __shared__ __attribute__((aligned(16))) float ess[2][GCN_WIDE_MAX_H];      // sums of e_tmp, e_tmp^2 over this workgroup's rows
-    __shared__ __attribute__((aligned(16))) float agg[2][GCN_WIDE_MAX_H];      // gated sums of the unit in progress: sum_j g Vn_j, sum_j g
+    __shared__ __attribute__((aligned(16))) float agg[2][2][GCN_WIDE_MAX_H];   // per unit in progress (slot u & 1): sum_j g Vn_j, sum_j g
     const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB, NKB = split_nkb(H);
     const EdgeSrc& S = a.src;
     clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
     clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
     clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
-    for (int k = threadIdx.x; k < 2 * GCN_WIDE_MAX_H; k += SFT) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; (&agg[0][0])[k] = 0.f; }
+    for (int k = threadIdx.x; k < 2 * GCN_WIDE_MAX_H; k += SFT) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; }
+    for (int k = threadIdx.x; k < 4 * GCN_WIDE_MAX_H; k += SFT) (&agg[0][0][0])[k] = 0.f;
     for (int e = threadIdx.x * 16; e < 3 * SPB; e += SFT * 16) *reinterpret_cast<u32x4*>(planes + e) = u32x4{0u, 0u, 0u, 0u};
     const int units = a.B * V * C;
-    const int njt = (V + 15) / 16;
     const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
     const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
+    const bool span = V >= 16 * SNS;
     __syncthreads();
     if (threadIdx.x >= STH) {
         // ---------------------------------------------------------------- staging wavefronts
         const int pt = threadIdx.x - STH, arow = pt >> 4, g0 = pt & 15;
         const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
         f32x4 val[SNS][WKA];
-        // rows 16 s + arow of the step (u, jt): layer input -> val (zeros outside the problem), written to e_out
-        auto produce = [&](int u, int jt, int ns) {
-            const int bi = u / C, c = u - bi * C;
+        // rows 16 s + arow of a step: layer input -> val (zeros outside the step), written to e_out
+        auto produce = [&](const FwdStep& st) {
 #pragma unroll
             for (int s = 0; s < SNS; ++s) {
 #pragma unroll
                 for (int k = 0; k < WKA; ++k) val[s][k] = f4zero();
-                if (s >= ns) continue;
-                const int j = (jt + s) * 16 + arow;
-                const bool jok = j < V;
-                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
+                if (16 * s >= st.n) continue;
+                const int off = 16 * s + arow;
+                const bool jok = off < st.n;
+                int j = st.j0 + min(off, st.n - 1), u = st.u;
+                if (j >= V) { j -= V; ++u; }
+                const int bi = u / C, c = u - bi * C;
+                const size_t erow = ((size_t)bi * V + j) * C + c;
                 if (S.mode == 1) {
                     f32x4 tp[WKA], ti[WKA];
 #pragma unroll
                     for (int k = 0; k < WKA; ++k) {
                         const int acol = 4 * (g0 + 16 * k);
-                        const size_t off = (jok && acol < H) ? erow * H + acol : 0;
-                        tp[k] = ld4(S.prev_tmp + off); ti[k] = ld4(S.prev_in + off);
+                        const size_t o = (jok && acol < H) ? erow * H + acol : 0;
+                        tp[k] = ld4(S.prev_tmp + o); ti[k] = ld4(S.prev_in + o);
                     }
                     const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
 #pragma unroll
@@ -256,12 +281,12 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
                     for (int k = 0; k < WKA; ++k) {
                         const int acol = 4 * (g0 + 16 * k);
                         if (jok && acol < H) {
-                            const size_t off = erow * H + acol;
+                            const size_t o = erow * H + acol;
                             f32x4 v;
-                            if (S.mode == 0) v = ld4(S.e_in + off);
+                            if (S.mode == 0) v = ld4(S.e_in + o);
                             else {
                                 v = ld4(&cl[CL_WE][acol]) * capv;
-                                if (S.e_out != nullptr) st4(S.e_out + off, v);
+                                if (S.e_out != nullptr) st4(S.e_out + o, v);
                             }
                             val[s][k] = v;
                         }
@@ -269,30 +294,28 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
                 }
             }
         };
-        if (u0 < u1) produce(u0, 0, min(SNS, njt));
+        int u = u0, j0 = 0;
+        if (u < u1) produce(fwd_step_at(u, j0, u1, V, span));
         ACCF_DECL;
-        for (int u = u0; u < u1; ++u) {
-            for (int jt = 0; jt < njt; jt += SNS) {
-                const int ns = min(SNS, njt - jt);
+        while (u < u1) {
+            const FwdStep st = fwd_step_at(u, j0, u1, V, span);
 #pragma unroll
-                for (int s = 0; s < SNS; ++s) {
-                    if (s >= ns) break;
+            for (int s = 0; s < SNS; ++s) {
+                if (16 * s >= st.n) break;
 #pragma unroll
-                    for (int k = 0; k < WKA; ++k) {
-                        const int g = g0 + 16 * k;
-                        if (4 * g < HP) split_put4(planes, 16 * s + arow, g, val[s][k]);
-                    }
+                for (int k = 0; k < WKA; ++k) {
+                    const int g = g0 + 16 * k;
+                    if (4 * g < HP) split_put4(planes, 16 * s + arow, g, val[s][k]);
                 }
-                ACCF(0);
-                __syncthreads();                    // the planes of this step are complete
-                ACCF(1);
-                int nu = u, nj = jt + SNS;
-                if (nj >= njt) { nu = u + 1; nj = 0; }
-                if (nu < u1) produce(nu, nj, min(SNS, njt - nj));
-                ACCF(2);
-                __syncthreads();                    // the product of this step is done: the planes may be overwritten
-                ACCF(5);
             }
+            ACCF(0);
+            __syncthreads();                    // the planes of this step are complete
+            ACCF(1);
+            fwd_step_next(u, j0, st.n, V);
+            if (u < u1) produce(fwd_step_at(u, j0, u1, V, span));
+            ACCF(2);
+            __syncthreads();                    // the product of this step is done: the planes may be overwritten
+            ACCF(5);
         }
         ACCF_END(threadIdx.x >> 6, threadIdx.x & 63);
         return;
@@ -300,88 +323,109 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
     // -------------------------------------------------------------------- multiplying wavefronts
     const SplitIdx ix = split_idx();
     ACCF_DECL;
-    for (int u = u0; u < u1; ++u) {
-        const int bi = u / C, c = u - bi * C, b = bi / V;
-        for (int jt = 0; jt < njt; jt += SNS) {
-            const int ns = min(SNS, njt - jt);
-            ACCF(0);
-            __syncthreads();
-            ACCF(1);
+    int u = u0, j0 = 0;
+    while (u < u1) {
+        const FwdStep st = fwd_step_at(u, j0, u1, V, span);
+        const int ns = (st.n + 15) >> 4;
+        // this lane's rows of the step: row j (of unit u, or of unit u + 1 past the end of unit u)
+        int jr[SNS];
+        bool rok[SNS], inb[SNS];
+#pragma unroll
+        for (int s = 0; s < SNS; ++s) {
+            const int off = 16 * s + ix.rs;
+            rok[s] = off < st.n;
+            int j = st.j0 + min(off, st.n - 1);
+            inb[s] = j >= V;
+            jr[s] = inb[s] ? j - V : j;
+        }
+        const bool two = st.j0 + st.n > V;              // the step holds rows of unit u + 1 as well
+        const int biA = u / C, cA = u - biA * C, bA = biA / V;
+        const int uB = two ? u + 1 : u;
+        const int biB = uB / C, cB = uB - biB * C, bB = biB / V;
+        ACCF(0);
+        __syncthreads();
+        ACCF(1);
 #pragma unroll 1
-            for (int kk = 0; kk < SKB8; ++kk) {
-                const int nb = ix.w + 8 * kk;
-                if (nb < NB) {
-                    const int bcol = 16 * nb + 4 * ix.q;
-                    // epilogue operands are requested before the product so that their latency hides under it
-                    const bool cok = bcol < H;
-                    f32x4 vej[SNS], vnj2[SNS];
-                    const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
+        for (int kk = 0; kk < SKB8; ++kk) {
+            const int nb = ix.w + 8 * kk;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                // epilogue operands are requested before the product so that their latency hides under it
+                const bool cok = bcol < H;
+                f32x4 vej[SNS], vnj2[SNS];
+                const f32x4 bu = ld4(a.bU + (cok ? bcol : 0));
+                const f32x4 veiA = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + bu;
+                const f32x4 veiB = ld4(a.Ve + (cok ? (size_t)uB * H + bcol : 0)) + bu;
+#pragma unroll
+                for (int s = 0; s < SNS; ++s) {
+                    const size_t nrow = (size_t)((inb[s] ? bB : bA) * V + jr[s]) * C + (inb[s] ? cB : cA);
+                    const size_t o = (cok && rok[s]) ? nrow * H + bcol : 0;
+                    vej[s] = ld4(a.Ve + o); vnj2[s] = ld4(a.Vn + o);
+                }
+                f32x4 et2[SNS];
+                split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, et2);
+                ACCF(2);
+                f32x4 t1 = f4zero(), t2 = f4zero(), nmA = f4zero(), dnA = f4zero(), nmB = f4zero(), dnB = f4zero();
+                if (cok) {
 #pragma unroll
                     for (int s = 0; s < SNS; ++s) {
-                        const int j = (jt + s) * 16 + ix.rs;
-                        const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
-                        vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
-                    }
-                    f32x4 et2[SNS];
-                    split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, et2);
-                    ACCF(2);
-                    f32x4 t1 = f4zero(), t2 = f4zero(), nm = f4zero(), dn = f4zero();
-                    if (cok) {
+                        if (s < ns && rok[s]) {
+                            const size_t erow = ((size_t)(inb[s] ? biB : biA) * V + jr[s]) * C + (inb[s] ? cB : cA);
+                            const f32x4 et = et2[s] + (inb[s] ? veiB : veiA) + vej[s];
+                            const f32x4 vnj = vnj2[s];
+                            st4(a.e_tmp + erow * H + bcol, et);
 #pragma unroll
-                        for (int s = 0; s < SNS; ++s) {
-                            const int j = (jt + s) * 16 + ix.rs;
-                            if (s < ns && j < V) {
-                                const size_t erow = ((size_t)bi * V + j) * C + c;
-                                const f32x4 et = et2[s] + base + vej[s];
-                                const f32x4 vnj = vnj2[s];
-                                st4(a.e_tmp + erow * H + bcol, et);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float g = sigmoidf_(et[r]);
-                                    nm[r] += g * vnj[r];
-                                    dn[r] += g;
-                                    t1[r] += et[r];
-                                    t2[r] += et[r] * et[r];
-                                }
+                            for (int r = 0; r < 4; ++r) {
+                                const float g = sigmoidf_(et[r]);
+                                const float gv = g * vnj[r];
+                                if (inb[s]) { nmB[r] += gv; dnB[r] += g; }
+                                else { nmA[r] += gv; dnA[r] += g; }
+                                t1[r] += et[r];
+                                t2[r] += et[r] * et[r];
                             }
                         }
                     }
-                    // sums over the step's rows, added by the lane that owns the four columns (same lane, same
-                    // address every time: fixed order, no atomics)
-                    wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
-                    wide_acc_cols(agg, bcol, ix.rs == 0 && cok, nm, dn);
-                    ACCF(3);
                 }
+                // sums over the step's rows, added by the lane that owns the four columns (same lane, same
+                // address every time: fixed order, no atomics)
+                wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
+                wide_acc_cols(agg[u & 1], bcol, ix.rs == 0 && cok, nmA, dnA);
+                if (two) wide_acc_cols(agg[uB & 1], bcol, ix.rs == 0 && cok, nmB, dnB);
+                ACCF(3);
             }
-            ACCF(4);
-            __syncthreads();
-            ACCF(5);
         }
-        // ---- unit end: the lane that accumulated these columns
+        // ---- unit u ends with this step: the lane that accumulated these columns finishes it
+        if (st.j0 + st.n >= V) {
 #pragma unroll
-        for (int k = 0; k < SKB8; ++k) {
-            const int nb = ix.w + 8 * k;
-            if (nb < NB) {
-                const int bcol = 16 * nb + 4 * ix.q;
-                if (ix.rs == 0 && bcol < H) {
-                    const f32x4 nm = ld4(&agg[0][bcol]), dn = ld4(&agg[1][bcol]);
-                    st4(&agg[0][bcol], f4zero()); st4(&agg[1][bcol], f4zero());
-                    f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
-                    if (a.mean_agg) {
-                        D = dn + 1e-20f;
+            for (int k = 0; k < SKB8; ++k) {
+                const int nb = ix.w + 8 * k;
+                if (nb < NB) {
+                    const int bcol = 16 * nb + 4 * ix.q;
+                    if (ix.rs == 0 && bcol < H) {
+                        float (*ag)[GCN_WIDE_MAX_H] = agg[u & 1];
+                        const f32x4 nm = ld4(&ag[0][bcol]), dn = ld4(&ag[1][bcol]);
+                        st4(&ag[0][bcol], f4zero()); st4(&ag[1][bcol], f4zero());
+                        f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
+                        if (a.mean_agg) {
+                            D = dn + 1e-20f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) A[r] = nm[r] * __builtin_amdgcn_rcpf(D[r]);
+                            for (int r = 0; r < 4; ++r) A[r] = nm[r] * __builtin_amdgcn_rcpf(D[r]);
+                        }
+                        const f32x4 xt = ld4(a.Ux + (size_t)u * H + bcol) + A;
+                        st4(a.x_tmp + (size_t)u * H + bcol, xt);
+                        st4(a.Aout + (size_t)u * H + bcol, A);
+                        st4(a.Dout + (size_t)u * H + bcol, D);
+                        // this lane is the only one that ever touches these four columns of pxs
+                        st4(&pxs[0][bcol], ld4(&pxs[0][bcol]) + xt);
+                        st4(&pxs[1][bcol], ld4(&pxs[1][bcol]) + xt * xt);
                     }
-                    const f32x4 xt = ld4(a.Ux + (size_t)u * H + bcol) + A;
-                    st4(a.x_tmp + (size_t)u * H + bcol, xt);
-                    st4(a.Aout + (size_t)u * H + bcol, A);
-                    st4(a.Dout + (size_t)u * H + bcol, D);
-                    // this lane is the only one that ever touches these four columns of pxs
-                    st4(&pxs[0][bcol], ld4(&pxs[0][bcol]) + xt);
-                    st4(&pxs[1][bcol], ld4(&pxs[1][bcol]) + xt * xt);
                 }
             }
         }
+        ACCF(4);
+        __syncthreads();
+        ACCF(5);
+        fwd_step_next(u, j0, st.n, V);
     }
 #pragma unroll
     for (int k = 0; k < SKB8; ++k) {
