@@ -446,11 +446,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="nsfnet_10_commodities")
     ap.add_argument("--batch", type=int, default=0, help="graphs per GPU (default: the config's batch_size)")
+    ap.add_argument("--layers", type=int, default=0, help="conv layers (default: the config's num_layers; tests use fewer)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-beam", action="store_true")
     ap.add_argument("--skip-sweep", action="store_true", help="skip the batch sweep (B = 20, 80, 320) of the headline workload")
     ap.add_argument("--skip-opt", action="store_true", help="skip the extra leg that adds the optimizer step")
+    ap.add_argument("--bucket-mb", type=float, default=8.0,
+                    help="with a process group: gradients of at least this many MB are averaged in buckets of this size that "
+                         "start while the backward pass still runs (eager launches); below it, one message after the step")
     ap.add_argument("--skip-large", action="store_true", help="skip the large_configs legs (the two large configurations at one graph per GPU)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the broadcast / all-reduce even with one rank "
@@ -496,6 +500,8 @@ def main():
     shape = dict(CONFIGS[args.config])
     if args.batch:
         shape["B"] = args.batch
+    if args.layers:
+        shape["L"] = args.layers
     B, V, C, H, Lr = shape["B"], shape["V"], shape["C"], shape["H"], shape["L"]
     batch = make_batch(B, V, C, shape["topology"], shape["cap_lo"], shape["cap_hi"], shape["dem_lo"], shape["dem_hi"],
                        seed=1234 + rank)
@@ -507,13 +513,23 @@ def main():
         D.broadcast_(cw)
         batch["edge_cw"] = cw.cpu().numpy()
     _stage("parameters broadcast")
-    step = HipTrainStep(model, B, device, use_graph=not args.no_graph)
+    # Large gradients (the H = 300, L = 30 configuration: 44 MB) are averaged in buckets behind per-layer completion
+    # events of the backward pass, which needs eager launches (milliseconds per kernel there: launch cost is nothing);
+    # small ones (0.7 MB at the headline) in one message after the replayed graph.
+    nparam_bytes = 4 * sum(p.numel() for p in model.parameters())
+    bucketed = dist is not None and nparam_bytes >= args.bucket_mb * 2 ** 20
+    use_graph = not args.no_graph and not bucketed
+    step = HipTrainStep(model, B, device, use_graph=use_graph)
     step.load_batch(batch["edges_capacity"], batch["commodities"][:, :, 2].astype(np.float32), batch["nodes"],
                     batch["edges_target"], batch["edge_cw"])
+    buckets = D.BucketedGradAllreduce(step, bucket_bytes=int(args.bucket_mb * 2 ** 20),
+                                      min_total_bytes=int(args.bucket_mb * 2 ** 20)) if bucketed else None
 
     def one_step():
         step.step()
-        if dist is not None:
+        if buckets is not None:
+            buckets.after_step()                    # per-bucket messages on a side stream, behind the layers' events
+        elif dist is not None:
             D.allreduce_mean_(step.flat_grad)       # one message; on RCCL the 1/N is part of the collective (AVG)
 
     for _ in range(args.warmup):
@@ -536,6 +552,7 @@ def main():
         D.allreduce_max_(t)
         elapsed = float(t.item())
     _stage("timed steps done")
+    loss = float(step.loss_out[0].item())           # of the last timed step
     # ---- the gradient all-reduce on its own: time between the end of the step's last kernel and the end of the
     # collective, over steps of their own (outside the headline's timed region)
     allreduce_ms = None
@@ -555,7 +572,6 @@ def main():
         t = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / n_ar, wall / n_ar * 1e3], dtype=torch.float64, device=device)
         D.allreduce_max_(t)
         allreduce_ms = [float(v) for v in t.tolist()]
-    loss = float(step.loss_out[0].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -629,7 +645,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs/gcn/{args.config}.json: V={V} C={C} H={H} L={Lr} mlp_layers=2 mean "
                                    f"aggregation, {B} graphs per GPU, train mode (dropout 0.3/0.2 on), fwd+bwd, "
-                                   f"{'HIP graph replay' if not args.no_graph else 'eager launches'}",
+                                   f"{'HIP graph replay' if use_graph else 'eager launches'}",
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "loss": round(loss, 5),
             # ranks of the RCCL (backend "nccl") process group the gradient all-reduce ran on; 0 = no process group
@@ -640,7 +656,10 @@ def main():
                 # max over ranks: device time between events recorded around the collective on the step's stream, and
                 # host wall time of the same stretch (collective launch to completion), step already finished
                 "ms_per_step": round(allreduce_ms[0], 4), "wall_ms_per_step": round(allreduce_ms[1], 4),
-                "overlap": "none (one message after the step's last kernel)"},
+                "overlap": ("none (one message after the step's last kernel)" if buckets is None else
+                            f"{len(buckets.buckets)} buckets of >= {args.bucket_mb:g} MB on a side stream, each behind the completion "
+                            f"event of its last layer (gcn_model_bwd_ev)"),
+                "buckets": None if buckets is None else [[int(lo) * 4, int(hi) * 4] for lo, hi, _ in buckets.buckets]},
             "roofline": roofline, "roofline_fwd": roofline_fwd, "with_optimizer": with_opt,
         }
         if world == 1 and not args.skip_cpu:

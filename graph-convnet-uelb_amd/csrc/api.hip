@@ -1110,6 +1110,14 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                   const long long* y_edges, const float* edge_cw, const float* const* P,
                   const unsigned long long* rng, const float* saved, const float* loss_out, const float* dloss,
                   const float* dy_pred, float* const* G, void* ws, size_t ws_bytes, void* stream) {
+    return gcn_model_bwd_ev(m, cap, demand, x_nodes, y_edges, edge_cw, P, rng, saved, loss_out, dloss, dy_pred, G, ws, ws_bytes,
+                            stream, nullptr);
+}
+
+int gcn_model_bwd_ev(const gcn_model_desc* m, const float* cap, const float* demand, const long long* x_nodes,
+                     const long long* y_edges, const float* edge_cw, const float* const* P,
+                     const unsigned long long* rng, const float* saved, const float* loss_out, const float* dloss,
+                     const float* dy_pred, float* const* G, void* ws, size_t ws_bytes, void* stream, void* const* done_events) {
     if (int rc = check_model(m)) return rc;
     if (!cap || !demand || !x_nodes || !P || !saved || !G || !ws) return fail(-1, "gcn_model_bwd: null pointer argument");
     if (m->has_labels && (!y_edges || !edge_cw || !loss_out)) return fail(-1, "gcn_model_bwd: has_labels needs y_edges, edge_cw, loss_out");
@@ -1120,6 +1128,13 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
     Bump b(ws, ws_bytes);
     const ModelBwdWs W = carve_model_bwd(p, b);
     if (!b.ok()) return fail(-2, "gcn_model_bwd: workspace too small (%zu < %zu bytes)", ws_bytes, b.off);
+    // done_events[k] (may be null, as may the array): recorded on the stream once every gradient of conv layer k
+    // (k < L) or of the edge MLP (k = L) is final
+    auto mark_done = [&](int k) -> int {
+        if (done_events != nullptr && done_events[k] != nullptr && hipEventRecord((hipEvent_t)done_events[k], st) != hipSuccess)
+            return fail(-3, "gcn_model_bwd_ev: cannot record the completion event of part %d", k);
+        return 0;
+    };
     const int H = d.H;
     const size_t nh = d.Rn * H, eh = d.Re * H, hh2 = (size_t)H * H;
     const float* x_act = saved + p.x_act;
@@ -1252,6 +1267,7 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
             GCN_PROF_PRE("k_reduce_slabs(head)");
             k_reduce_slabs<<<dim3(red_grid(jobs), jobs.n, 1), GCN_BLOCK, 0, st>>>(jobs);
             GCN_CHECK_LAUNCH("k_reduce_slabs(head)");
+            if (int rc = mark_done(p.L)) return rc;          // the edge MLP's gradients are final
         }
     }
     if (d.MT > 4) {
@@ -1307,6 +1323,8 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                     k_reduce_slabs<<<dim3(red_grid(jobs), nj, 1), GCN_BLOCK, 0, st>>>(jobs);
                     GCN_CHECK_LAUNCH("k_reduce_slabs(layer)");
                 }
+                // layer l + 1 is final now: its products were just reduced, its BatchNorm gradients one launch earlier
+                if (l + 1 < p.L) { if (int rc3 = mark_done(l + 1)) return rc3; }
             } else {
                 DISPATCH_MT(d.MT, if constexpr (MT != 0) GCN_LAUNCH_TIMED("k_wgrad", (k_wgrad<MT>), nb, GCN_BLOCK, H, pr, jobs, map));
             }
@@ -1442,6 +1460,12 @@ int gcn_model_bwd(const gcn_model_desc* m, const float* cap, const float* demand
                 d.B * d.V, d.C, H, m->n_emb, W.emb_g, W.emb_cnt, G[0], G[1], jobs, map);
             GCN_CHECK_LAUNCH("k_bwd_final");
         }
+    }
+    // Whatever was not marked on the way is final now: layer 0 (and the embeddings) on every path; up to 64 channels
+    // the gradients of all layers are finished by launches shared between layers, so every part is marked here.
+    if (done_events != nullptr) {
+        if (d.MT > 4) { if (int rc = mark_done(0)) return rc; }
+        else for (int k = 0; k <= p.L; ++k) { if (int rc = mark_done(k)) return rc; }
     }
     return 0;
 }

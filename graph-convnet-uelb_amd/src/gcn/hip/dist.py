@@ -112,15 +112,74 @@ def allreduce_max_(t, group=None):
 
 def allreduce_mean_grads(params, group=None):
     """Mean over ranks of the .grad tensors of params, as one all-reduce of their concatenation (for steps that
-    go through autograd and therefore have no flat gradient buffer)."""
+    go through autograd and therefore have no flat gradient buffer).  Every parameter takes part on every rank, zeros
+    standing in for a missing .grad (which then becomes the mean of the others'): the message has the same length on all
+    ranks whatever each of them happened to differentiate."""
     if world() == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = list(params)
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     allreduce_mean_(flat, group)
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    for p in params:
+        piece = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = piece.clone()
+        else:
+            p.grad.copy_(piece)
+        off += p.numel()
+
+class BucketedGradAllreduce:
+    """Gradient averaging that starts while the backward pass still runs (the counterpart of DistributedDataParallel's
+    buckets for HipTrainStep; the reference's nn.DataParallel, src/gcn/train/trainer.py:54, reduces after backward()).
+
+    The backward pass finishes the layers from the top down and records an event per finished part
+    (HipTrainStep.set_done_events / gcn_model_bwd_ev).  Consecutive parts are grouped into buckets of at least
+    `bucket_bytes`; `after_step()` queues, per bucket, "wait for the bucket's last part, all-reduce its range of
+    flat_grad" on a side stream, so a bucket travels over the links while the layers below it are still being
+    differentiated; the last bucket (layer 0 and the embeddings) follows the end of the step.  `wait()` makes the
+    current stream wait for all of them.  Below `min_total_bytes` of gradients one message after the step is cheaper
+    (latency bound) and `active` is False: call allreduce_mean_(step.flat_grad) instead."""
+
+    def __init__(self, step, bucket_bytes=8 << 20, min_total_bytes=8 << 20, group=None):
+        self.step, self.group = step, group
+        self.active = bool(active() and step.flat_grad.numel() * 4 >= min_total_bytes and not step.use_graph)
+        self.buckets = []           # (lo, hi, index of the event to wait for or None = end of the step)
+        if not self.active:
+            return
+        nl = step.model.num_layers
+        ranges = step.layer_grad_ranges()
+        order = [nl] + list(range(nl - 1, 0, -1))             # parts in the order they finish: MLP, layers L-1 .. 1
+        # the MLP sits behind the layers in flat_grad, so it is a bucket of its own; the layers below it form runs
+        self.buckets.append((ranges[nl][0], ranges[nl][1], nl))
+        hi, size = None, 0
+        for k in order[1:]:
+            lo_k, hi_k = ranges[k]
+            if hi is None:
+                hi = hi_k
+            size += (hi_k - lo_k) * 4
+            if size >= bucket_bytes:
+                self.buckets.append((lo_k, hi, k))
+                hi, size = None, 0
+        # what is left, layer 0 and the embeddings: final with the step's last kernel
+        self.buckets.append((0, hi if hi is not None else ranges[0][1], None))
+        need = {b[2] for b in self.buckets if b[2] is not None}
+        self.events = [torch.cuda.Event() if k in need else None for k in range(nl + 1)]
+        step.set_done_events(self.events)
+        self.side = torch.cuda.Stream(step.device)
+        self.end = torch.cuda.Event()
+
+    def after_step(self):
+        """Call right after step.step(): queues the bucket all-reduces behind their events."""
+        if not self.active:
+            return allreduce_mean_(self.step.flat_grad, self.group)
+        cur = torch.cuda.current_stream(self.step.device)
+        self.end.record(cur)
+        with torch.cuda.stream(self.side):
+            for lo, hi, k in self.buckets:
+                self.side.wait_event(self.events[k] if k is not None else self.end)
+                allreduce_mean_(self.step.flat_grad[lo:hi], self.group)
+        cur.wait_stream(self.side)
+        return self.step.flat_grad

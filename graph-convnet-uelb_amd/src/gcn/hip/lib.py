@@ -99,6 +99,8 @@ def _declare(lib):
     lib.gcn_model_bwd.argtypes = [POINTER(ModelDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   POINTER(c_void_p), c_void_p, c_size_t, c_void_p]
+    lib.gcn_model_bwd_ev.restype = c_int
+    lib.gcn_model_bwd_ev.argtypes = lib.gcn_model_bwd.argtypes + [POINTER(c_void_p)]
     lib.gcn_loss_ws_bytes.restype = c_size_t
     lib.gcn_loss_ws_bytes.argtypes = [c_int, c_int, c_int]
     lib.gcn_loss_edges_fwd.restype = c_int

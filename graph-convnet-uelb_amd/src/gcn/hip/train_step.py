@@ -38,6 +38,8 @@ class HipTrainStep:
             offs.append(tot)
             tot += (n + 3) // 4 * 4          # keep every view 16-byte aligned
         self.flat_grad = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.grad_offsets, self.grad_total = offs, tot      # float offsets of the parameters inside flat_grad
+        self.done_events = None                             # see set_done_events
         self.grad_views = [self.flat_grad[o:o + n].view_as(p) for o, n, p in zip(offs, sizes, self.params)]
         for p, g in zip(self.params, self.grad_views):
             p.grad = g
@@ -93,11 +95,42 @@ class HipTrainStep:
                                L.ptr(self.y_pred), L.ptr(self.loss_out), L.ptr(self.counts), L.ptr(self.flags),
                                L.ptr(self.saved), L.ptr(self.ws), self.ws.numel(), st)
         L.check(rc, "gcn_model_fwd")
-        rc = lib.gcn_model_bwd(ctypes.byref(d), L.ptr(self.cap), L.ptr(self.demand), L.ptr(self.x_nodes),
-                               L.ptr(self.y_edges), L.ptr(self.edge_cw), self._param_ptrs, L.ptr(self.rng),
-                               L.ptr(self.saved), L.ptr(self.loss_out), L.ptr(self.dloss), None, self._grad_ptrs,
-                               L.ptr(self.ws), self.ws.numel(), st)
-        L.check(rc, "gcn_model_bwd")
+        rc = lib.gcn_model_bwd_ev(ctypes.byref(d), L.ptr(self.cap), L.ptr(self.demand), L.ptr(self.x_nodes),
+                                  L.ptr(self.y_edges), L.ptr(self.edge_cw), self._param_ptrs, L.ptr(self.rng),
+                                  L.ptr(self.saved), L.ptr(self.loss_out), L.ptr(self.dloss), None, self._grad_ptrs,
+                                  L.ptr(self.ws), self.ws.numel(), st, self.done_events)
+        L.check(rc, "gcn_model_bwd_ev")
+
+    def layer_grad_ranges(self):
+        """Float ranges [lo, hi) of flat_grad: entry k < L holds the gradients of conv layer k, entry L those of the edge
+        MLP, entry L + 1 the embeddings (parameters are laid out embeddings, layers 0..L-1, MLP)."""
+        nl = self.model.num_layers
+        per = (len(self.params) - 3 - 2 * self.model.mlp_layers) // max(nl, 1)
+        offs = self.grad_offsets + [self.grad_total]
+        ranges = [(offs[3 + per * k], offs[3 + per * (k + 1)]) for k in range(nl)]
+        ranges.append((offs[3 + per * nl], self.grad_total))
+        ranges.append((0, offs[3]))
+        return ranges
+
+    def set_done_events(self, events):
+        """events: None, or L + 1 entries (torch.cuda.Event or None): entry k is recorded by the backward pass once the
+        gradients of conv layer k (k < L) or of the edge MLP (k = L) are final (gcn_model_bwd_ev).  Eager launches only:
+        a captured graph is replayed as a whole."""
+        if events is None:
+            self.done_events = None
+            return
+        if self.use_graph:
+            raise L.GcnHipError("completion events need eager launches (use_graph=False)")
+        if len(events) != self.model.num_layers + 1:
+            raise L.GcnHipError("one event per conv layer plus one for the edge MLP")
+        arr = (ctypes.c_void_p * len(events))()
+        with torch.cuda.device(self.device):
+            for k, ev in enumerate(events):
+                if ev is not None:
+                    ev.record()                     # creates the underlying event
+                    arr[k] = ev.cuda_event
+        self._done_event_objs = list(events)        # keep them alive
+        self.done_events = arr
 
     def _step_body(self):
         # new dropout masks every step: the forward call advances the step word of self.rng on the device

@@ -242,13 +242,19 @@ class ReinforcementLearningStrategy(BaseTrainingStrategy):
 
     def backward_step(self, loss, optimizer, accumulation_steps=1, batch_num=0):
         (loss / accumulation_steps).backward()
-        params = [p for group in optimizer.param_groups for p in group['params'] if p.grad is not None]
-        if (batch_num + 1) % accumulation_steps == 0:
-            # mean over the ranks first, then norm and clip: clip(mean(g_r)), what one process on the whole batch computes
-            D.allreduce_mean_grads(params)
+        every = [p for group in optimizer.param_groups for p in group['params']]
+        last_micro_step = (batch_num + 1) % accumulation_steps == 0
+        if last_micro_step:
+            # mean over the ranks first, then norm and clip: clip(mean(g_r)), what one process on the whole batch computes.
+            # Over the fixed parameter list (zeros for a missing .grad), so that every rank sends the same message
+            D.allreduce_mean_grads(every)
+        params = [p for p in every if p.grad is not None]
         with torch.no_grad():
             total = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in params])).item() if params else 0.0
-        self.grad_norm_history.append(total)
+        # the history the explosion detector looks at holds averaged gradients only: under several ranks the norm of
+        # a micro-step before the all-reduce is a local one and would differ from rank to rank
+        if last_micro_step or not D.active() or D.world() == 1:
+            self.grad_norm_history.append(total)
         if len(self.grad_norm_history) > self.grad_norm_history_size:
             self.grad_norm_history.pop(0)
         self.last_grad_explosion = False

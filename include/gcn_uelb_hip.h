@@ -139,6 +139,20 @@ int gcn_model_bwd(const gcn_model_desc* d, const float* cap, const float* demand
                   const float* dloss, const float* dy_pred, float* const* grads,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* gcn_model_bwd that also tells the caller when parts of the gradient are final, so that a data-parallel trainer can
+ * start averaging them over the ranks while the rest of the backward pass still runs (the reference has no such hook:
+ * its nn.DataParallel reduces all gradients after backward(), src/gcn/train/trainer.py:54; torch's DistributedDataParallel
+ * buckets are the model).  done_events: NULL, or L + 1 event handles (hipEvent_t; entries may be NULL): entry k < L is
+ * recorded on `stream` once every gradient of conv layer k is final, entry L once those of the edge MLP are.  Layers
+ * finish from the top down; layer 0 and the embeddings are final when the call's last kernel is (entry 0 is recorded
+ * there).  Up to 64 channels the layers' gradients are finished by shared launches at the end: all entries are
+ * recorded after the last kernel. */
+int gcn_model_bwd_ev(const gcn_model_desc* d, const float* cap, const float* demand, const long long* x_nodes,
+                     const long long* y_edges, const float* edge_cw, const float* const* params,
+                     const unsigned long long* rng, const float* saved, const float* loss_out,
+                     const float* dloss, const float* dy_pred, float* const* grads,
+                     void* ws, size_t ws_bytes, void* stream, void* const* done_events);
+
 /* ------------------------------------------------------------------------------------------------
  * Stand-alone loss and edge-error metric on existing two-class logits [B,V,V,C,2].
  * Replaces loss_edges (src/gcn/models/model_utils.py:51-78) and edge_error / _edge_error (:255-308)

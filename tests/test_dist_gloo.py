@@ -46,9 +46,11 @@ def _worker(rank, world, port, out):
         q = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2)), torch.nn.Parameter(torch.zeros(1))]
         q[0].grad = torch.full((3,), float(rank))
         q[1].grad = torch.full((2, 2), 2.0 * rank + 1.0)
+        if rank == 1:
+            q[2].grad = torch.full((1,), 4.0)     # a parameter only one rank differentiated: the message still has one length
         D.allreduce_mean_grads(q)
         assert torch.allclose(q[0].grad, torch.full((3,), 0.5)) and torch.allclose(q[1].grad, torch.full((2, 2), 2.0))
-        assert q[2].grad is None
+        assert q[2].grad is not None and torch.allclose(q[2].grad, torch.full((1,), 2.0))      # zeros stood in on rank 0
         out.put((rank, "ok"))
     except Exception as ex:  # pragma: no cover
         out.put((rank, repr(ex)))

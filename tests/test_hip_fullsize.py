@@ -14,7 +14,10 @@ two correct implementations may put such an element on either side of the ReLU, 
 that element's whole contribution.  The tests do not tolerate that away: the oracle is given the ReLU pattern the
 HIP path actually used (read back with gcn_bn_relu_pattern from the activations the forward pass saved), and every
 gradient entry must then meet the bound.  That the handed-over pattern differs from the oracle's own only at ties is
-checked too: wherever the two disagree, the oracle's BatchNorm output must be zero at the parity tolerance (below 1e-4 of the tensor's largest output).
+checked too: wherever the two disagree, the oracle's BatchNorm output must be within float32 rounding of zero (below 2e-5 of
+the tensor's largest output).  Gradients are held to 1e-4 of each tensor's own maximum, with the two exceptions that
+test_hip_parity.assert_grads_close spells out (tensors that are zero in exact arithmetic; tensors on which the float32 oracle
+itself is further than 1e-4 from the float64 one).
 """
 import ctypes
 
@@ -24,9 +27,11 @@ import torch
 
 from oracle import gcn_oracle
 from conftest import report
-from test_hip_parity import RTOL, _Cfg, _dev
+from test_hip_parity import RTOL, ZERO_REL, _Cfg, _dev, assert_grads_close
 
 pytestmark = pytest.mark.gpu
+
+TIE = 2e-5      # see _check_config: how far from zero a BatchNorm output may be for two correct float32 runs to disagree on its sign
 
 
 def _rel_err(got, ref):
@@ -108,10 +113,11 @@ def _check_config(name, B, seed=99, init_seed=5):
                 n = int(differ.sum())
                 ties[k] += n
                 if n:
-                    # "a tie" = zero at the parity tolerance: below 1e-4 of the largest BatchNorm output of the tensor
+                    # "a tie" = a BatchNorm output within float32 rounding of zero: below TIE of the tensor's largest
+                    # output (measured: up to 1.3e-5 after 30 layers at H = 300, 3.3e-6 at 200 nodes x 100 commodities)
                     worst, top = float(bn[differ].abs().max()), float(bn.abs().max())
                     worst_tie = max(worst_tie, worst / top)
-                    assert worst <= RTOL * top, f"layer {l}: ReLU pattern differs at a BatchNorm output of {worst:.3e} (largest {top:.3e})"
+                    assert worst <= TIE * top, f"layer {l}: ReLU pattern differs at a BatchNorm output of {worst:.3e} (largest {top:.3e})"
             del aux, me, mx
         del x, e
     # (2) with that pattern, everything within 1e-4
@@ -126,17 +132,26 @@ def _check_config(name, B, seed=99, init_seed=5):
     worst = []
     for (k, p), g in zip(model.named_parameters(), hip.step.grad_views):
         errv, scale = _rel_err(g, gref[k])
-        worst.append((errv / max(scale, 1e-6 * gmax), k, errv, scale))
+        if scale >= ZERO_REL * gmax:
+            worst.append((errv / scale, k))
     worst.sort(reverse=True)
+
+    def grads32():
+        # the same oracle in float32 (plain PyTorch on the GPU), with the same ReLU pattern: the yardstick for tensors
+        # that float32 arithmetic cannot hold to RTOL (only computed when a tensor exceeds it)
+        P32 = {k: v.detach().float().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        _, _, g32 = gcn_oracle.model_loss_and_grads_checkpointed(P32, ocfg, cap.float(), comm[:, :, 2].float(), nodes, y_edges,
+                                                                 batch["edge_cw"], relu_masks=hip.relu_masks)
+        return g32
+
+    beyond = assert_grads_close(((k, g) for (k, p), g in zip(model.named_parameters(), hip.step.grad_views)), gref, grads32)
     yerr, yscale = _rel_err(hip.step.y_pred, y_ref)
     report(f"[fullsize {name}] B={B} L={Lr}: loss {loss:.6f} (oracle {float(loss_ref):.6f}); y_pred err {yerr / yscale:.2e}; "
            f"ReLU decisions that differ from the float64 oracle's, edge/node: {ties} (largest |BN| among them "
-           f"{worst_tie:.1e} of the tensor's maximum); worst gradient tensors, err / max(scale, floor): "
-           + ", ".join(f"{k} {r:.2e}" for r, k, _, _ in worst[:3]))
-    for r, k, errv, scale in worst:
-        # gradients that are zero in exact arithmetic (biases in front of a BatchNorm, the node branch of the last
-        # layer) get an absolute floor of 1e-6 x the largest gradient of the model
-        assert errv <= RTOL * scale + 1e-6 * gmax, f"grad {k}: max err {errv:.3e} vs scale {scale:.3e} (every entry, no tolerated fraction)"
+           f"{worst_tie:.1e} of the tensor's maximum); worst gradient tensors, err / own maximum: "
+           + ", ".join(f"{k} {r:.2e}" for r, k in worst[:3])
+           + ("; beyond 1e-4 and held to the float32 oracle's own error instead (tensor, HIP, float32 oracle): "
+              + ", ".join(f"{k} {a:.2e} {b:.2e}" for k, a, b in beyond) if beyond else ""))
     return hip, batch
 
 

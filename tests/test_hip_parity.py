@@ -37,6 +37,53 @@ def assert_close(got, ref, what, atol=0.0):
     assert err <= RTOL * scale + atol, f"{what}: max err {err:.3e} vs scale {scale:.3e} (atol {atol:.1e})"
 
 
+# Parameter gradients.  Every tensor must agree with the float64 oracle to RTOL of the tensor's own maximum: no
+# absolute allowance scaled by the model's largest gradient.  Two kinds of tensor cannot be held to that, and each is
+# recognised from the oracle's own numbers, not waved through by a blanket floor:
+#   * tensors that are zero in exact arithmetic (node_feat.U.bias in front of the node BatchNorm, the node branch of
+#     a model's last layer): the float64 oracle itself returns its rounding noise for them (below ZERO_REL of the largest
+#     gradient of the model), so "relative to its own maximum" has no meaning; they must stay below ZERO_ABS of the
+#     largest gradient (or, like the next kind, within F32_SLACK of what the float32 oracle returns for them: over 10^6
+#     rows the float32 rounding noise of such a sum reaches 1e-5 of the largest gradient);
+#   * tensors that are small remainders of large cancelling sums, where plain float32 arithmetic cannot reach RTOL: the
+#     same oracle run in float32 (plain PyTorch) is the yardstick, and the HIP result may be at most F32_SLACK times
+#     as far from the float64 oracle as that run is.  (Measured at the H = 300, L = 30 configuration: the float32 oracle
+#     is 2.0e-4 off on gcn_layers.1.node_feat.{U,V}.weight, the HIP path 1.8e-4.  The factor is what two float32 evaluation
+#     orders of the same cancelling sum can differ by: at H = 16, L = 30 a bias gradient 2e-9 times the size of the model's
+#     largest gradient comes out 1.3e-4 off in the float32 oracle and 3.4e-4 off in the HIP path.)
+ZERO_REL = 1e-9
+ZERO_ABS = 1e-7
+F32_SLACK = 4.0
+
+
+def assert_grads_close(named_grads, ref64, ref32, what=""):
+    """named_grads: iterable of (name, HIP gradient); ref64: name -> float64 oracle gradient; ref32: name -> the oracle's
+    gradient in float32 arithmetic, or a callable that computes that dict when it is first needed."""
+    gmax = max(float(torch.as_tensor(v).abs().max()) for v in ref64.values())
+    cache = {}
+
+    def f32(k):
+        if "d" not in cache:
+            cache["d"] = ref32() if callable(ref32) else ref32
+        return torch.as_tensor(cache["d"][k]).detach().double().cpu()
+
+    worst = []
+    for k, g in named_grads:
+        got = torch.nan_to_num(g.detach().double().cpu())
+        ref = torch.as_tensor(ref64[k]).detach().double().cpu()
+        assert got.shape == ref.shape, f"{what}grad {k}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+        err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+        zero = scale < ZERO_REL * gmax
+        bound = ZERO_ABS * gmax if zero else RTOL * scale
+        if err > bound:
+            e32 = float((f32(k) - ref).abs().max())
+            bound = max(bound, F32_SLACK * e32)
+            worst.append((k, err / max(scale, ZERO_ABS * gmax), e32 / max(scale, ZERO_ABS * gmax)))
+            assert err <= bound, (f"{what}grad {k}{' (zero in exact arithmetic)' if zero else ''}: max err {err:.3e}, its maximum "
+                                  f"{scale:.3e}, largest gradient {gmax:.3e}; the float32 oracle is {e32:.3e} off")
+    return worst
+
+
 def _relu_margin(x, e, P, agg):
     """Smallest |BatchNorm output| of the layer on this input.  A ReLU input within fp32 rounding (~1e-6 here) of
     zero may legitimately fall on either side in two correct implementations, which moves the gradients by a
@@ -91,9 +138,17 @@ def test_layer_forward_backward_matches_oracle(B, V, C, H, agg):
     assert_close(e2, e1, "e_new")
     assert_close(xh.grad, xo.grad, "dx_in")
     assert_close(eh.grad, eo.grad, "de_in")
-    gmax = max(float(P[k].grad.abs().max()) for k in P)
-    for k, p in layer.named_parameters():
-        assert_close(p.grad, P[k].grad, "grad " + k, atol=1e-6 * gmax)
+    assert_grads_close(((k, q.grad) for k, q in layer.named_parameters()), _layer_grads64(x, e, gx, ge, P, agg), {k: P[k].grad for k in P})
+
+
+def _layer_grads64(x, e, gx, ge, P, agg, mx=None, me=None, p=0.0):
+    """Parameter gradients of the oracle layer in float64 (optionally with given dropout masks applied to the outputs)."""
+    P64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in P.items()}
+    x1, e1, _ = gcn_oracle.gcn_layer(x.double(), e.double(), P64, "", agg)
+    if mx is not None:
+        x1, e1 = x1 * mx.double() / (1 - p), e1 * me.double() / (1 - p)
+    ((x1 * gx.double()).sum() + (e1 * ge.double()).sum()).backward()
+    return {k: P64[k].grad for k in P64}
 
 
 def _build_model(g, dev):
@@ -126,9 +181,20 @@ def test_model_matches_reference_golden(path):
         assert loss is None
         (y * t(g["in_dy_pred"])).sum().backward()
     assert_close(y, g["out_y_pred"], "y_pred")
-    gmax = max(float(np.abs(v).max()) for k, v in g.items() if k.startswith("grad."))
-    for k, p in model.named_parameters():
-        assert_close(p.grad, g["grad." + k], "grad " + k, atol=1e-6 * gmax)
+    # gradients: the float64 oracle on the golden's weights and inputs is the reference, the reference implementation's
+    # own float32 gradients (the golden file) are the float32 yardstick
+    P64 = {k: v.detach().double().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ocfg = dict(num_layers=int(g["cfg_L"]), mlp_layers=int(g["cfg_mlp_layers"]), aggregation=str(g["cfg_aggregation"]),
+                voc_edges_out=int(g["cfg_voc"]))
+    c64, d64, n64 = torch.from_numpy(g["in_cap"]).double(), torch.from_numpy(g["in_comm"])[:, :, 2].double(), torch.from_numpy(g["in_x_nodes"])
+    if int(g["cfg_voc"]) == 2:
+        _, l64 = gcn_oracle.model_forward(P64, ocfg, c64, d64, n64, torch.from_numpy(g["in_y_edges"]), g["in_edge_cw"])
+        l64.backward()
+    else:
+        y64, _ = gcn_oracle.model_forward(P64, ocfg, c64, d64, n64, compute_loss=False, mask_invalid_edges=bool(g["cfg_mask"]))
+        (y64 * torch.from_numpy(g["in_dy_pred"]).double()).sum().backward()
+    ref64 = {k: (P64[k].grad if P64[k].grad is not None else torch.zeros_like(P64[k])) for k in P64}
+    assert_grads_close(((k, p.grad) for k, p in model.named_parameters()), ref64, {k: g["grad." + k] for k in ref64})
 
 
 @pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (2, 2, 384, 96, 2), (2, 2, 384, 304, 2)])
@@ -172,9 +238,8 @@ def test_layer_train_mode_dropout_semantics(B, V, C, H, chunk):
     assert_close(e1, ee, "e_new (train)")
     assert_close(xh.grad, xo.grad, "dx_in (train)")
     assert_close(eh.grad, eo.grad, "de_in (train)")
-    gmax = max(float(P[k].grad.abs().max()) for k in P)
-    for k, q in layer.named_parameters():
-        assert_close(q.grad, P[k].grad, "grad " + k, atol=1e-6 * gmax)
+    assert_grads_close(((k, q.grad) for k, q in layer.named_parameters()), _layer_grads64(x, e, gx, ge, P, "mean", mx, me, p),
+                       {k: P[k].grad for k in P}, "train mode: ")
     x2, e2 = layer(xh.detach(), eh.detach())
     assert not torch.equal(e1 != 0, e2 != 0)
     layer.eval()
@@ -261,9 +326,13 @@ def test_wide_layer_many_steps_per_workgroup():
     assert_close(e2, e1, "e_new")
     assert_close(xh.grad, xo.grad, "dx_in")
     assert_close(eh.grad, eo.grad, "de_in")
-    gmax = max(float(P[k].grad.abs().max()) for k in P)
-    for k, p in layer.named_parameters():
-        assert_close(p.grad, P[k].grad, "grad " + k, atol=1e-5 * gmax)
+    def grads32():
+        P32 = {k: v.detach().float().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+        a, b, _ = gcn_oracle.gcn_layer(x, e, P32, "", "mean")
+        ((a * gx).sum() + (b * ge).sum()).backward()
+        return {k: P32[k].grad for k in P32}
+
+    assert_grads_close(((k, p.grad) for k, p in layer.named_parameters()), {k: P[k].grad for k in P}, grads32)
 
 
 @pytest.mark.parametrize("H,L,mlp_layers,voc", [(80, 2, 2, 2), (128, 3, 2, 2), (300, 2, 2, 2), (96, 2, 1, 2), (72, 2, 2, 1),
@@ -333,9 +402,18 @@ def test_wide_model_matches_oracle(H, L, mlp_layers, voc):
         (y * gy.to(dev)).sum().backward()
     assert_close(y, y_ref, "y_pred")
     ref = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}
-    gmax = max(float(g.abs().max()) for g in ref.values())
-    for k, p in model.named_parameters():
-        assert_close(p.grad, ref[k], "grad " + k, atol=1e-6 * gmax)
+
+    def grads32():
+        P32 = {k: v.detach().float().clone().requires_grad_(True) for k, v in P.items()}
+        if voc == 2:
+            _, l32 = gcn_oracle.model_forward(P32, ocfg, cap, comm[:, :, 2].float(), nodes, y_edges, cw)
+            l32.backward()
+        else:
+            y32, _ = gcn_oracle.model_forward(P32, ocfg, cap, comm[:, :, 2].float(), nodes, compute_loss=False, mask_invalid_edges=True)
+            (y32 * gy).sum().backward()
+        return {k: (P32[k].grad if P32[k].grad is not None else torch.zeros_like(P32[k])) for k in P32}
+
+    assert_grads_close(((k, p.grad) for k, p in model.named_parameters()), ref, grads32)
 
 
 @pytest.mark.parametrize("H,mlp_layers", [(96, 4), (80, 3), (48, 4)])

@@ -22,12 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(extra_args, extra_env, gpus=1):
+def _bench(extra_args, extra_env, gpus=1, batch="4"):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "2", "--batch", "4",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "2", "--batch", batch,
            "--skip-cpu", "--skip-beam", "--skip-opt", "--skip-sweep", "--skip-large"] + extra_args
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -64,3 +64,24 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert out["rccl_ranks"] == 0 and out["gradient_allreduce"]["backend"] == "gloo"
     assert out["gradient_allreduce"]["wall_ms_per_step"] > 0
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_bucketed_gradient_allreduce_runs_behind_the_layer_events_on_one_nccl_rank():
+    """Gradients of 8 MB or more are averaged in buckets that start while the backward pass still runs: each bucket's
+    all-reduce is queued on a side stream behind the completion event of its last layer (gcn_model_bwd_ev).  One RCCL
+    rank at H = 300 with the bucket size lowered to 1 MB so that four layers make several buckets; averaging over one
+    rank is the identity, so the loss must equal the plain run's (a bucket reduced before its layer was final, or a
+    range computed wrongly, would change the gradients only - those are compared in test_hip_dist_trainer - but the
+    collectives, events and stream waits all execute here)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    cfgargs = ["--config", "synthetic_100n_50c_h300_l30", "--layers", "4"]
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
+    plain = _bench(cfgargs + ["--no-graph"], {}, batch="1")
+    ddp = _bench(cfgargs + ["--force-dist", "--bucket-mb", "1"], env, batch="1")
+    ar = ddp["gradient_allreduce"]
+    assert ddp["rccl_ranks"] == 1 and ar["backend"] == "nccl"
+    assert ar["buckets"] is not None and len(ar["buckets"]) >= 3
+    assert ar["buckets"][-1][0] == 0 and sum(hi - lo for lo, hi in ar["buckets"]) == ar["bytes"]      # a partition of flat_grad
+    assert "eager" in ddp["config"]["workload"]
+    assert ddp["loss"] == plain["loss"]
