@@ -20,7 +20,7 @@
 #include "kernels_strip.hpp"
 #include "kernels_strip2.hpp"
 #include "kernels_wide.hpp"
-#include "kernels_wide_bf.hpp"
+#include "kernels_tn_bf.hpp"
 #include "sampler.hpp"
 #include "dataset.hpp"
 
@@ -589,12 +589,19 @@ template <int MT>
 int launch_tn(int H, const TnProblems& pr, int nprob, int max_slices, hipStream_t st) {
     GCN_PROF_PRE("k_gemm_tn");
     if constexpr (MT == 0) {
-        // 86 KiB of LDS per workgroup: above the 64 KiB a kernel gets without asking (set per call: the attribute
+        // 132 KiB (86 KiB) of LDS per workgroup: above the 64 KiB a kernel gets without asking (set per call: the attribute
         // belongs to the current device)
-        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_w),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TnWideLds));
-        if (attr != hipSuccess) return fail(-3, "k_gemm_tn_w: cannot reserve %zu bytes of LDS", sizeof(TnWideLds));
-        k_gemm_tn_w<<<dim3(max_slices, 1, nprob), 512, sizeof(TnWideLds), st>>>(H, pr);
+        if (H <= TS_MAX_H) {         // bf16 pieces on the matrix pipe; needs a free column of the padded H for the bias sums
+            const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_ws),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS);
+            if (attr != hipSuccess) return fail(-3, "k_gemm_tn_ws: cannot reserve %d bytes of LDS", TS_LDS);
+            k_gemm_tn_ws<<<dim3(max_slices, 1, nprob), TS_TH, TS_LDS, st>>>(H, pr);
+        } else {
+            const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_w),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TnWideLds));
+            if (attr != hipSuccess) return fail(-3, "k_gemm_tn_w: cannot reserve %zu bytes of LDS", sizeof(TnWideLds));
+            k_gemm_tn_w<<<dim3(max_slices, 1, nprob), 512, sizeof(TnWideLds), st>>>(H, pr);
+        }
     }
     else k_gemm_tn2<MT><<<dim3(max_slices, 1, nprob), 64 * MT, 0, st>>>(H, pr);
     GCN_CHECK_LAUNCH("k_gemm_tn");
