@@ -284,7 +284,9 @@ int red_grid(const ReduceJobs& jobs) {
 int tn_slices(size_t rows, int H) {
     const size_t ntiles = (rows + 15) / 16;
     if (const char* e = tune_env("GCN_TUNE_SLICES")) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, (size_t)atoi(e)));
-    if (H > 64) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, 256));
+    // wide kernels: one workgroup per CU, and a workgroup clears 132 KiB of LDS and writes a slab of H x H + H floats
+    // whatever its share of rows: at least 8 chunks of 16 rows each
+    if (H > 64) return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 8, 256));
     const size_t s = ((size_t)(3.8 * std::sqrt((double)ntiles)) + 8) / 16 * 16;
     return (int)std::max<size_t>(1, std::min<size_t>(ntiles / 4, std::min<size_t>(std::max<size_t>(s, 16), 768)));   // 768: flat beyond at 10^6 row tiles
 }
