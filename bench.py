@@ -54,9 +54,10 @@ def build_model(shape, device):
     from src.gcn.models.gcn_model import ResidualGatedGCNModel
     cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
               hidden_dim=shape["H"], num_layers=shape["L"], mlp_layers=2, aggregation="mean",
-              # the key the reference's config files carry (nsfnet_10_commodities.json:38); the model reads it and, like the
-              # reference, never uses it: the layers drop with p = 0.3 and the MLP with p = 0.2 (gcn_model.py:31,39,42)
-              dropout_rate=0.5)
+              # dropout_rate: the key the reference's config files carry (nsfnet_10_commodities.json:38); the model reads
+              # it and, like the reference, never uses it: the layers drop with p = 0.3 and the MLP with p = 0.2
+              # (gcn_model.py:31,39,42), which is what the workload string reports
+              dropout_rate=shape.get("dropout_rate", 0.3))
     torch.manual_seed(0)                      # identical initial weights on every rank
     return ResidualGatedGCNModel(cfg, torch.float32, torch.long).to(device)
 

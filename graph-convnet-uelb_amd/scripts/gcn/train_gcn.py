@@ -13,6 +13,7 @@ import torch  # noqa: E402
 
 from src.common.config.config_manager import ConfigManager  # noqa: E402
 from src.gcn.train.evaluator import Evaluator  # noqa: E402
+from src.gcn.train.metrics import GCNMetricsLogger  # noqa: E402
 from src.gcn.train.trainer import Trainer  # noqa: E402
 
 
@@ -30,12 +31,22 @@ def main():
     f, l = manager.get_dtypes()
     trainer = Trainer(config, f, l)
     evaluator = Evaluator(config, f, l, strategy=trainer.strategy)      # as the reference (train_gcn.py:46)
-    trainer.train(evaluator, None)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    # the reference builds its logger unconditionally (train_gcn.py:47); here rank 0 keeps the books
+    metrics_logger = GCNMetricsLogger(os.environ.get('GCN_UELB_LOG_DIR', config.get('log_dir', 'logs'))) if rank0 and config.get('metrics_logger', True) else None
+    trainer.train(evaluator, metrics_logger)
+    info = {'config_file': args.config, 'mode': 'training', 'max_epochs': config.get('max_epochs', 0),
+            'num_train_data': config.get('num_train_data', 0), 'num_test_data': config.get('num_test_data', 0),
+            'num_val_data': config.get('num_val_data', 0)}
     if config.get('num_test_data', 0) >= config.batch_size:
         res = evaluator.evaluate(trainer.get_model(), None, mode='test')
-        if int(os.environ.get("RANK", "0")) == 0:
+        if rank0:
             print(f"test: loss {res[1]:.4f}  mean max load factor {res[2]:.4f}  infeasible% {res[5]:.1f}  "
                   f"completion% {res[6]:.1f}", flush=True)
+    if metrics_logger is not None:
+        metrics_logger.print_summary(info)
+        paths = metrics_logger.save_results(info)
+        print(f"results written to {paths[0]}", flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -157,9 +157,13 @@ def load():
             raise GcnHipError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
                               f"(hipcc --offload-arch=gfx950); there is no fallback path")
         stamp = LIB_PATH + ".srchash"
+        if not os.path.exists(stamp) and os.path.isdir(os.path.join(_PKG_ROOT, "csrc")):
+            import warnings
+            warnings.warn(f"{LIB_PATH} carries no source stamp ({stamp} is missing): it cannot be told from a library "
+                          f"built from older sources; `python __graft_entry__.py build` writes the stamp", RuntimeWarning)
         if os.path.exists(stamp) and os.path.isdir(os.path.join(_PKG_ROOT, "csrc")):
             with open(stamp) as fh:
-                built_from = fh.read().strip()
+                built_from = (fh.read().split() or [''])[0]      # first word: the hash; build flags may follow
             if built_from != source_hash():
                 raise GcnHipError(f"{LIB_PATH} was built from other sources than those in {_PKG_ROOT}/csrc "
                                   f"(stored hash {built_from[:12]}, tree {source_hash()[:12]}): rebuild it with "

@@ -78,10 +78,10 @@ class Evaluator:
         start = time.time()
         with torch.no_grad():
             for batch in dataset:
-                d = prep.prepare_batch_data(batch, device)
                 paths_t = None
                 if self.strategy is not None:                                   # evaluator.py:124-128
-                    batch_data = self.strategy.prepare_batch_data(batch, device)
+                    # one host-to-device copy per batch: the strategy's dict carries the two tensors used below
+                    d = batch_data = self.strategy.prepare_batch_data(batch, device)
                     loss, metrics = self.strategy.compute_loss(net, batch_data, device)
                     mean_lf = float(metrics.get('mean_load_factor', 0.0))
                     pred_paths = metrics.get('pred_paths', None)
@@ -89,6 +89,7 @@ class Evaluator:
                         paths_t = paths_to_tensors(pred_paths, len(pred_paths), d['batch_commodities'].shape[1],
                                                    d['x_edges_capacity'].shape[1], device)
                 else:                                                           # evaluator.py:129-141
+                    d = prep.prepare_batch_data(batch, device)
                     if edge_cw is None:
                         labels = batch.edges_target.ravel()
                         classes, counts = np.unique(labels, return_counts=True)

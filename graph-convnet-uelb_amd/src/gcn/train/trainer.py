@@ -188,12 +188,19 @@ class Trainer:
         return f"model_{self._get_config_hash()}_{tag}.pt"
 
     def save_model(self, epoch, loss, save_latest=True):
-        """Checkpoint with the reference's keys and file names (trainer.py:375-412); rank 0 writes."""
+        """Checkpoint with the reference's file names and top-level keys (trainer.py:375-412); rank 0 writes.
+        The reference saves the state dict of an nn.DataParallel wrapper, whose parameter names start with ``module.``
+        (trainer.py:382), and loads it back into the wrapper with strict key matching.  The model here is not wrapped,
+        so its names carry no prefix; with ``checkpoint_module_prefix: true`` in the config the prefix is written, and
+        the file then loads in the reference as it is.  load_checkpoint accepts both forms."""
         if D.rank() != 0:
             return None
         os.makedirs(self.models_dir, exist_ok=True)
         cfg = self.config
-        ckpt = {'epoch': epoch, 'model_state_dict': self.net.state_dict(), 'optimizer_state_dict': self.optimizer.state_dict(),
+        state = self.net.state_dict()
+        if cfg.get('checkpoint_module_prefix', False):
+            state = {'module.' + k: v for k, v in state.items()}
+        ckpt = {'epoch': epoch, 'model_state_dict': state, 'optimizer_state_dict': self.optimizer.state_dict(),
                 'loss': loss, 'config_hash': self._get_config_hash(),
                 'config': {'hidden_dim': cfg.hidden_dim, 'num_layers': cfg.num_layers, 'mlp_layers': cfg.mlp_layers,
                            'node_dim': cfg.get('node_dim'), 'voc_nodes_in': cfg.num_commodities * 3,

@@ -123,3 +123,33 @@ def test_launch_plan_is_sane_over_a_grid_of_shapes():
             if H <= 64:
                 assert plan["grid_fwd"] % 8 == 0
             assert plan["two_blocks"] == (H in (32, 64) and B * V * V * C >= 300000), (B, V, C, H, plan)
+
+
+def test_metrics_logger_books_what_the_trainer_reports(tmp_path):
+    """The logger takes the calls the reference's trainer makes (trainer.py:514, 541, 553, 571) and reports the
+    reference's final-metric keys (metrics.py:104-117)."""
+    import json
+    from src.gcn.train.metrics import GCNMetricsLogger, metrics_to_str
+    lg = GCNMetricsLogger(str(tmp_path))
+    for epoch in range(3):
+        lg.log_train_metrics(1.0 / (epoch + 1), 10.0 - epoch, 2.0)
+        lg.log_rl_metrics(epoch, {"reward": -1.5 + epoch, "entropy": 0.3, "load_factor": 1.2, "complete_paths_rate": 90.0})
+        lg.log_val_metrics(80.0 + epoch, 0.5, epoch=epoch, comp_rate=95.0, comp_sample_rate=60.0)
+    lg.log_test_metrics(85.0, 0.25, epoch=2, comp_rate=97.0, comp_sample_rate=70.0)
+    m = lg.get_final_metrics()
+    assert set(m) == {"final_train_loss", "final_edge_error", "final_val_approximation_rate", "final_test_approximation_rate",
+                      "best_val_approximation_rate", "best_test_approximation_rate", "total_train_time", "total_test_time",
+                      "avg_train_time_per_epoch", "avg_test_time_per_epoch"}
+    assert m["final_train_loss"] == 1.0 / 3 and m["final_edge_error"] == 8.0 and m["best_val_approximation_rate"] == 82.0
+    assert m["total_train_time"] == 6.0 and m["avg_train_time_per_epoch"] == 2.0 and m["total_test_time"] == 0.25
+    assert lg.val_comp_rate_list == [95.0] * 3 and lg.test_comp_sample_rate_list == [70.0] and lg.rl_reward_list == [-1.5, -0.5, 0.5]
+    (csv,) = [f for f in os.listdir(tmp_path) if f.startswith("rl_gcn_metrics_")]
+    rows = open(os.path.join(tmp_path, csv)).read().strip().split("\n")
+    assert rows[0].startswith("epoch,reward,reward_std,advantage,advantage_std,entropy,load_factor,load_factor_std,baseline,")
+    assert len(rows) == 4 and rows[3].startswith("2,0.500000,0.000000,")
+    jpath, tpath = lg.save_results({"num_train_data": 10, "num_test_data": 4, "config_file": "x.json"})
+    booked = json.load(open(jpath))
+    assert booked["train_loss_list"] == lg.train_loss_list and booked["time_per_data"]["total_train_samples"] == 30
+    assert "final_train_loss" in open(tpath).read()
+    line = metrics_to_str(3, 1.5, 1e-3, 0.25, 1.1, 1.0, 90.0, 0.0, comp_rate=99.0)
+    assert line.startswith("epoch:03\texecution time:1.50000000s\tlr:1.00e-03\tloss:0.2500\t") and line.endswith("comp_rate:99.00%")

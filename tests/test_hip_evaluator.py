@@ -170,3 +170,20 @@ def test_trainer_schedule_checkpoints_and_pretrained_head_conversion(tmp_path, m
     assert torch.equal(sd["mlp_edges.output_layer.weight"].cpu(), w2[1:2] - w2[0:1])
     assert torch.equal(sd["mlp_edges.output_layer.bias"].cpu(), b2[1:2] - b2[0:1])
     assert torch.equal(sd["gcn_layers.0.edge_feat.U.weight"].cpu(), sup["module.gcn_layers.0.edge_feat.U.weight"])
+    # checkpoint_module_prefix: the file carries the reference's key names (trainer.py:382 saves an nn.DataParallel
+    # wrapper), loads strictly into such a wrapper, and reads back here
+    cfg_p = _cfg(tmp_path, "supervised", max_epochs=3, val_every=2, decay_rate=2.0, expt_name="t", checkpoint_module_prefix=True)
+    tr_p = Trainer(cfg_p, torch.float32, torch.long)
+    saved = tr_p.save_model(0, 1.0)
+    ck = torch.load(saved, map_location="cpu", weights_only=True)
+    assert all(k.startswith("module.") for k in ck["model_state_dict"])
+    from src.gcn.models.gcn_model import ResidualGatedGCNModel
+    wrapper = torch.nn.DataParallel(ResidualGatedGCNModel(cfg_p, torch.float32, torch.long))
+    wrapper.load_state_dict(ck["model_state_dict"], strict=True)
+    other = Trainer(cfg_p, torch.float32, torch.long)
+    with torch.no_grad():
+        for q in other.get_model().parameters():
+            q.add_(1.0)
+    assert other.load_checkpoint(saved) == 0
+    for (k, a), b in zip(tr_p.get_model().state_dict().items(), other.get_model().state_dict().values()):
+        assert torch.equal(a, b), k

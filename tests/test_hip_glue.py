@@ -89,12 +89,20 @@ def test_graph_captured_train_step_matches_autograd_path():
 
 
 def test_train_script_runs_on_synthetic_data(tmp_path):
-    env = dict(os.environ, GCN_UELB_MODEL_ROOT=str(tmp_path))
+    env = dict(os.environ, GCN_UELB_MODEL_ROOT=str(tmp_path), GCN_UELB_LOG_DIR=str(tmp_path / "logs"))
     r = subprocess.run([sys.executable, os.path.join(PKG, "scripts", "gcn", "train_gcn.py"), "--config",
                         os.path.join(PKG, "configs", "gcn", "smoke_synthetic.json")], cwd=PKG, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "epoch 2/2" in r.stdout and "test: loss" in r.stdout
+    # the metrics logger the script passes to Trainer.train saw both epochs
+    import glob
+    import json
+    (res,) = glob.glob(str(tmp_path / "logs" / "training_results_*.json"))
+    with open(res) as f:
+        booked = json.load(f)
+    assert len(booked["train_loss_list"]) == 2 and len(booked["train_time_list"]) == 2
+    assert booked["val_approximation_rate_list"] and booked["config_info"]["mode"] == "training"
 
 
 def test_fused_adam_matches_torch_adam():
