@@ -163,11 +163,18 @@ __device__ inline void beam_fill_edge_caps(const BeamLds& L, const float* __rest
     __syncthreads();
 }
 
-// Scores of one commodity per list entry from the gathered table ye_bc [nnz] into LDS.
-__device__ inline void beam_load_edge_scores(const BeamLds& L, const float* __restrict__ ye_bc, int nnz) {
-    if (L.y_e == nullptr) return;
-    for (int e = threadIdx.x; e < nnz; e += 64) L.y_e[e] = ye_bc[e];
+// Scores of one commodity per list entry from the gathered table ye_bc [nnz] into LDS.  Returns (to every lane) whether
+// all of them are <= 0, as log-probabilities are: a path's score then never rises when the path is extended.
+__device__ inline int beam_load_edge_scores(const BeamLds& L, const float* __restrict__ ye_bc, int nnz) {
+    if (L.y_e == nullptr) return 0;
+    int pos = 0;
+    for (int e = threadIdx.x; e < nnz; e += 64) {
+        const float v = ye_bc[e];
+        L.y_e[e] = v;
+        pos |= !(v <= 0.f) ? 1 : 0;          // a NaN counts as "may rise"
+    }
     __syncthreads();
+    return __any(pos) ? 0 : 1;
 }
 
 // y_e [B][C][nnzc]: the scores y[b][row][col][c] of every list entry, gathered once so that a search reads its scores
@@ -237,8 +244,13 @@ __device__ __forceinline__ int beam_wave_scan(int x) {
 // Returns the length of the best path (written to L.best_path), 0 if none.  All 64 lanes must call it.
 // Paths are kept as back pointers: bp_node[t][r] is the node at position t of the beam of rank r at that depth and
 // bp_par[t][r] the rank of the beam it extends; a path is written out only when a beam on the target becomes the result.
+// monotone != 0: every edge score of this commodity is <= 0 (beam_load_edge_scores).  Scores are then non-increasing
+// along a path (fp32 addition of a non-positive term never rounds upwards), so once no beam off the target has a score
+// above the best result's, no later result can be strictly better and the search ends with the result the reference's
+// run-until-the-queue-is-empty loop (:141-169) returns - typically a few steps past the shortest path instead of a walk
+// over up to V nodes.
 __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const float* cap_e, const float* __restrict__ yb, int V,
-                                     int C, int K, int src, int dst, float demand, int check_demand) {
+                                     int C, int K, int src, int dst, float demand, int check_demand, int monotone = 0) {
     const int lane = threadIdx.x;
     const int VW = (V + 31) / 32;
     int gen = 0, nb = 1, len = 1;
@@ -275,6 +287,10 @@ __device__ inline int beam_commodity(const BeamLds& L, const float* capm, const 
                     }
                 }
             }
+        }
+        if (monotone && have_best && K <= 64) {
+            const float my_score = lane < nb ? gscore[lane] : 0.f;
+            if (!__any(my_node >= 0 && my_node != dst && my_score > best_score)) break;
         }
         // expansion: candidate (k, n) in beam-rank order, n ascending
         const int ncand = nb * V;
@@ -494,10 +510,10 @@ __global__ __launch_bounds__(64) void k_beam_search(
         if (run_mask && !run_mask[b]) return;
         const int nnz_u = beam_load_adjacency(L, adj_ptr ? adj_ptr + (size_t)b * (V + 1) : nullptr, adj_col ? adj_col + (size_t)b * nnzc : nullptr, V);
         beam_fill_edge_caps(L, cap + (size_t)b * V * V, V);
-        if (nnz_u >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz_u);
+        const int mono = nnz_u >= 0 ? beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz_u) : 0;
         const long long* cm = comm + ((size_t)b * C + c) * 3;
         const int len = beam_commodity(L, cap + (size_t)b * V * V, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0],
-                                       (int)cm[1], 0.f, 0);
+                                       (int)cm[1], 0.f, 0, mono);
         int* pb = paths + ((size_t)b * C + c) * PL;
         for (int t = lane; t < PL; t += 64) pb[t] = t < len ? (int)L.best_path[t] : -1;
         if (lane == 0) {
@@ -587,8 +603,8 @@ __global__ __launch_bounds__(64) void k_beam_search(
                 for (int t = lane; t < len; t += 64) L.best_path[t] = (unsigned short)spec_paths[((size_t)b * C + c) * PL + t];
                 __syncthreads();
             } else {
-                if (nnz >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz);
-                len = beam_commodity(L, strict ? wcap : cap_b, L.cap_e, yb + c, V, C, K, s, d, demand, 1);
+                const int mono = nnz >= 0 ? beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz) : 0;
+                len = beam_commodity(L, strict ? wcap : cap_b, L.cap_e, yb + c, V, C, K, s, d, demand, 1, mono);
             }
             if (len == 0) { ok = 0; break; }
             for (int t = lane; t < PL; t += 64) pb[(size_t)c * PL + t] = t < len ? (int)L.best_path[t] : -1;
@@ -671,14 +687,14 @@ __global__ __launch_bounds__(64) void k_beam_spec(
     } else {
         beam_fill_edge_caps(L, cap_b, V);
     }
-    if (nnz >= 0) beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz);
+    const int mono = nnz >= 0 ? beam_load_edge_scores(L, y_e + ((size_t)b * C + c) * nnzc, nnz) : 0;
     if (L.wcap) {
         for (int t = lane; t < V * V; t += 64) L.wcap[t] = dense[t];
         __syncthreads();
     }
     const long long* cm = comm + ((size_t)b * C + c) * 3;
     const int len = beam_commodity(L, L.wcap ? L.wcap : dense, L.cap_e, y + (size_t)b * V * V * C + c, V, C, K, (int)cm[0], (int)cm[1],
-                                   (float)cm[2], 1);
+                                   (float)cm[2], 1, mono);
     for (int t = lane; t < len; t += 64) spec_paths[((size_t)b * C + c) * PL + t] = (int)L.best_path[t];
     if (lane == 0) spec_len[(size_t)b * C + c] = len;
 }

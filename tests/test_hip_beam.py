@@ -128,6 +128,29 @@ def test_beam_matches_c_oracle_at_benchmark_sizes(algo, strict, V, C, K, B):
         assert int(a.attempts.sum()) == used
 
 
+@pytest.mark.parametrize("algo,strict,V,C,K,B,shift", [("deterministic", True, 14, 12, 10, 12, 1.5), ("deterministic", True, 60, 5, 10, 4, 0.7),
+                                                        ("unconstrained", False, 30, 6, 8, 5, 2.0), ("deterministic", True, 30, 6, 4, 6, 0.0)])
+def test_beam_scores_above_zero_are_searched_to_the_end(algo, strict, V, C, K, B, shift):
+    """With log-probabilities (all scores <= 0) a search stops once no beam can beat the best result; scores above
+    zero can rise along a path, so such inputs must take the reference's run-until-empty walk.  shift moves part of the
+    scores above zero (0.0: the largest score is exactly zero, still non-positive)."""
+    from src.common.synthetic import make_batch
+    dev = _dev()
+    rng = np.random.default_rng(V * 7 + C)
+    b = make_batch(B, V, C, "nsfnet" if V == 14 else "random", 1000, 5000, 5, 500, seed=3 * V + C)
+    y = (np.log(rng.random((B, V, V, C)).astype(np.float32) * 0.98 + 0.01) + np.float32(shift)).astype(np.float32)
+    if shift == 0.0:
+        y[rng.random(y.shape) < 0.1] = np.float32(0.0)
+    else:
+        assert (y > 0).any() and (y < 0).any()
+    rp, rl, rf, _, _ = beam_oracle_c.search(y, b["edges_capacity"], b["commodities"], K, algo, strict)
+    a = _make(algo, y, b["edges_capacity"], b["commodities"], K, strict, 5, dev)
+    a.search()
+    assert np.array_equal(a.paths_tensor.cpu().numpy(), rp)
+    assert np.array_equal(a.path_len.cpu().numpy(), rl)
+    assert np.array_equal(a.feasible_per_graph.cpu().numpy().astype(np.int32), rf)
+
+
 @pytest.mark.parametrize("V,density,K,C,B,strict", [(40, 0.8, 10, 6, 6, True), (60, 0.33, 16, 5, 4, True),
                                                       (60, 0.33, 16, 5, 4, False), (48, 1.0, 8, 4, 3, True)])
 def test_beam_dense_graphs_match_c_oracle(V, density, K, C, B, strict):
