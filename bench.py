@@ -82,6 +82,55 @@ def measured_traffic(config, graphs_per_gpu, kernel_prefix):
     return None, False
 
 
+def live_traffic(config, graphs_per_gpu, layers, kernel_prefixes, timeout_s=150):
+    """HBM bytes per launch of the named kernels, measured now: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: one counter per pass, counters only, no tracing), two eager steps
+    each, on the same configuration.  FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes),
+    WRITE_SIZE is taken as reported, both KiB.  Returns {prefix: bytes} for the kernels found, {} if a pass fails
+    (no rocprofv3, a time limit, an unreadable result): the caller then falls back to the committed table."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    # not from inside a profiled run (tools/*.sh run this script under rocprofv3: no profiler inside a profiler)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith("ROCPROF") for k in os.environ)
+    if shutil.which("rocprofv3") is None or profiled:
+        return {}
+    sums = {}
+    tmp = tempfile.mkdtemp(prefix="gcn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["timeout", "-s", "KILL", str(timeout_s), "rocprofv3", "--pmc", ctr, "--kernel-include-regex", "k_edge_",
+                   "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--config", config,
+                   "--batch", str(graphs_per_gpu), "--layers", str(layers), "--steps", "2", "--warmup", "1", "--no-graph",
+                   "--skip-cpu", "--skip-beam", "--skip-sweep", "--skip-large", "--skip-opt", "--skip-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return {}
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == ctr:
+                            acc.setdefault(row["Kernel_Name"].replace("void ", ""), []).append(float(row["Counter_Value"]))
+            for pre in kernel_prefixes:
+                vals = [x for k, v in acc.items() if k.startswith(pre) for x in v]
+                if not vals:
+                    return {}
+                kb = sum(vals) / len(vals)
+                sums[pre] = sums.get(pre, 0.0) + (2.0 * kb if ctr == "FETCH_SIZE" else kb) * 1024.0
+    except Exception:
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: int(round(v)) for k, v in sums.items()}
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -280,8 +329,11 @@ def large_configs(device, rank):
                  "edge_fwd": edge_kernel_roofline(kf, True, tk[kf][0], tk[kf][1], B, V, C, H, plan["two_blocks"])}
             if H > 64:
                 ms_tn, n_tn = tk["k_gemm_tn"]
-                e["weight_gradient"] = {"kernel": "k_gemm_tn_w (four products per launch: the edge product and three node products)",
-                                        "avg_launch_us": round(ms_tn * 1e3, 2), "launches_timed": n_tn}
+                flops_tn = 2.0 * H * H * (B * V * V * C + 3.0 * B * V * C)
+                e["weight_gradient"] = {"kernel": "k_gemm_tn_ws (four products per launch: the edge product and three node products; "
+                                                  "bf16 pieces, v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
+                                        "avg_launch_us": round(ms_tn * 1e3, 2), "launches_timed": n_tn,
+                                        "achieved_TFLOPs_fp32_products": round(flops_tn / (ms_tn * 1e-3) / 1e12, 1)}
             out[name] = e
             del eager, model
             torch.cuda.empty_cache()
@@ -457,6 +509,8 @@ def main():
                     help="with a process group: gradients of at least this many MB are averaged in buckets of this size that "
                          "start while the backward pass still runs (eager launches); below it, one message after the step")
     ap.add_argument("--skip-large", action="store_true", help="skip the large_configs legs (the two large configurations at one graph per GPU)")
+    ap.add_argument("--skip-traffic", action="store_true",
+                    help="do not start the two rocprofv3 counter passes that measure the edge kernels' HBM traffic")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the broadcast / all-reduce even with one rank "
                          "(executes the RCCL path on a single GPU)")
@@ -626,12 +680,20 @@ def main():
         tk = time_kernels(eager, lib, [kb, kf], nprof)
         roofline = edge_kernel_roofline(kb, False, tk[kb][0], tk[kb][1], B, V, C, H, plan["two_blocks"])
         roofline_fwd = edge_kernel_roofline(kf, True, tk[kf][0], tk[kf][1], B, V, C, H, plan["two_blocks"])
-        traffic, traffic_stale = measured_traffic(args.config, B, kb)
-        roofline["traffic"] = traffic
-        roofline["traffic_stale"] = traffic_stale
-        traffic, traffic_stale = measured_traffic(args.config, B, kf)
-        roofline_fwd["traffic"] = traffic
-        roofline_fwd["traffic_stale"] = traffic_stale
+        # HBM traffic per launch: measured by counter passes this run starts itself; the committed table of earlier
+        # passes (profiles/pmc_traffic.json, only if taken on these sources) stands in where that is not possible
+        live = {} if (args.skip_traffic or world != 1) else live_traffic(args.config, B, Lr, [kb, kf])
+        for rf, name in ((roofline, kb), (roofline_fwd, kf)):
+            if name in live:
+                rf["traffic"] = live[name]
+                rf["traffic_stale"] = False
+                rf["traffic_source"] = ("two rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE) started by this run, "
+                                        "two eager steps each")
+            else:
+                rf["traffic"], rf["traffic_stale"] = measured_traffic(args.config, B, name)
+                rf["traffic_source"] = "profiles/pmc_traffic.json (committed counter passes)"
+            if rf["traffic"]:
+                rf["traffic_over_algorithmic"] = round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
         step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
         roofline["whole_step_algorithmic_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
         for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore

@@ -28,7 +28,7 @@ def _bench(extra_args, extra_env, gpus=1, batch="4"):
         env.pop(k, None)
     env.update(extra_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "2", "--batch", batch,
-           "--skip-cpu", "--skip-beam", "--skip-opt", "--skip-sweep", "--skip-large"] + extra_args
+           "--skip-cpu", "--skip-beam", "--skip-opt", "--skip-sweep", "--skip-large", "--skip-traffic"] + extra_args
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -50,6 +50,28 @@ def test_one_rank_nccl_process_group_runs_and_matches_plain_run():
     # the collective is timed on its own (events around it on the step's stream, and host wall time)
     assert ddp["gradient_allreduce"]["ms_per_step"] > 0 and ddp["gradient_allreduce"]["wall_ms_per_step"] > 0
     assert plain["roofline"]["kernel"].startswith("k_edge_bwd") and plain["roofline_fwd"]["kernel"].startswith("k_edge_fwd")
+
+
+def test_bench_measures_the_edge_kernels_hbm_traffic_itself():
+    """Without --skip-traffic the run starts two rocprofv3 counter passes of its own and reports their result as
+    roofline.traffic: at least the algorithmic bytes (every edge tensor of the model is read or written once), and not
+    a multiple of them (re-reads would show here first)."""
+    import shutil
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "20",
+                        "--skip-cpu", "--skip-beam", "--skip-opt", "--skip-sweep", "--skip-large"], cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for key in ("roofline", "roofline_fwd"):
+        rf = out[key]
+        assert rf["traffic_source"].startswith("two rocprofv3 --pmc passes"), rf
+        assert rf["traffic"] > 0 and rf["traffic_stale"] is False
+        assert 0.9 <= rf["traffic_over_algorithmic"] <= 3.0, rf
 
 
 def test_bench_starts_its_own_ranks_without_a_launcher():
