@@ -43,7 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "graph-convnet-uelb_amd"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA: 256 CUs x 256 flop per cycle x 2.4 GHz
-DOMINANT_KERNEL = "k_edge_bwd"         # k_edge_bwd4 (H of 2 or 4 column blocks), k_edge_bwd3, k_edge_bwd_w above 64
+DOMINANT_KERNEL = "k_edge_bwd"         # k_edge_bwd4 (H of 2 or 4 column blocks), k_edge_bwd3, k_edge_bwd_ws above 64
 
 
 class Cfg(dict):

@@ -4,7 +4,7 @@
 //   * phase B: wavefront w walks the 16-column blocks w, w + 4, ... of the output,
 //   * the H x H weights do not fit in registers or LDS: each 16-row tile streams the weight rows of its
 //     column block from memory (L2-resident) as MFMA A operands.
-// One LDS tile per operand (single buffered, two barriers per step); the two edge kernels take up to three 16-row
+// One LDS tile per operand (single buffered, two barriers per step); the head kernels take up to three 16-row
 // tiles per step against one fetch of the weight rows (wide_gemm_ns).  The math of each kernel is stated above its
 // argument block in kernels_fused.hpp.
 #pragma once
@@ -296,447 +296,7 @@ __device__ unsigned long long g_phase_acc[1024][12][8];
 #define GCN_STAMP_F(slot) GCN_STAMP(slot)
 #define GCN_STAMP_B(slot) do { } while (0)
 #endif
-// ------------------------------------------------------------------------------------------------
-// Edge forward (EdgeFwdArgs).  Workgroups take contiguous ranges of (b, i, c) units and walk their j tiles WNS at a
-// time (16 WNS rows in LDS per step).  partial layout [gridDim.x][4][H].
-// ------------------------------------------------------------------------------------------------
-#ifndef GCN_WIDE_PIPE_F
-#define GCN_WIDE_PIPE_F 0
-#endif
-__global__ __launch_bounds__(256, 2) void k_edge_fwd_w(EdgeFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[16 * WNS][WLS];
-    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GCN_WIDE_MAX_H];
-    __shared__ __attribute__((aligned(16))) float pxs[2][GCN_WIDE_MAX_H];      // sums of x_tmp, x_tmp^2 over this workgroup's units
-    __shared__ __attribute__((aligned(16))) float ess[2][GCN_WIDE_MAX_H];      // sums of e_tmp, e_tmp^2 over this workgroup's rows
-    const WideIdx ix = wide_idx();
-    const int H = a.H, V = a.V, C = a.C, NB = (H + 15) / 16, HP = 16 * NB;
-    const EdgeSrc& S = a.src;
-    clds_fill(cl[CL_PMEAN], S.mode == 1 ? S.pmean : nullptr, H, HP); clds_fill(cl[CL_PRSTD], S.mode == 1 ? S.prstd : nullptr, H, HP);
-    clds_fill(cl[CL_PGAMMA], S.mode == 1 ? S.pgamma : nullptr, H, HP); clds_fill(cl[CL_PBETA], S.mode == 1 ? S.pbeta : nullptr, H, HP);
-    clds_fill(cl[CL_WE], S.mode == 2 ? S.we : nullptr, H, HP);
-    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) { (&pxs[0][0])[k] = 0.f; (&ess[0][0])[k] = 0.f; }
-    wide_zero_pad(tile, NB, ix.t);
-    const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
-    const rsrc_t rW = make_rsrc(a.WU, (uint32_t)H * H * 4);
-    const int units = a.B * V * C;
-    const int njt = (V + 15) / 16;
-    const int per = (units + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
-#ifdef GCN_PHASE_TRACE
-    int tstep = 0;
-#endif
-    __syncthreads();
-    ACCF_DECL;
-    for (int u = u0; u < u1; ++u) {
-        const int bi = u / C, c = u - bi * C, b = bi / V;
-        f32x4 num[WKB], den[WKB];
-#pragma unroll
-        for (int k = 0; k < WKB; ++k) { num[k] = f4zero(); den[k] = f4zero(); }
-        for (int jt = 0; jt < njt; jt += WNS) {
-            const int ns = min(WNS, njt - jt);
-            GCN_STAMP_F(0);
-            // ---- phase A: rows 16 s + arow of the step; all loads of a row are requested before the first is used
-#pragma unroll
-            for (int s = 0; s < WNS; ++s) {
-                if (s >= ns) break;
-                const int j = (jt + s) * 16 + ix.arow;
-                const bool jok = j < V;
-                const size_t erow = ((size_t)bi * V + min(j, V - 1)) * C + c;
-                float (*trow) = tile[16 * s + ix.arow];
-                if (S.mode == 1) {
-                    f32x4 pt[WKA], pi[WKA];
-#pragma unroll
-                    for (int k = 0; k < WKA; ++k) {
-                        const int acol = 4 * (ix.g0 + 16 * k);
-                        const size_t off = (jok && acol < H) ? erow * H + acol : 0;
-                        pt[k] = ld4(S.prev_tmp + off); pi[k] = ld4(S.prev_in + off);
-                    }
-                    const uint32_t rh = dc.on ? drop_rowhash(dc, (uint32_t)erow) : 0u;
-#pragma unroll
-                    for (int k = 0; k < WKA; ++k) {
-                        const int g = ix.g0 + 16 * k, acol = 4 * g;
-                        if (acol < HP) {
-                            f32x4 val = f4zero();
-                            if (jok && acol < H) {
-                                val = bn_relu_res4(pt[k], pi[k], &cl[CL_PMEAN][acol], &cl[CL_PRSTD][acol], &cl[CL_PGAMMA][acol], &cl[CL_PBETA][acol]);
-                                if (dc.on) val *= drop_mul4(dc, rh, g);
-                                if (S.e_out != nullptr) st4(S.e_out + erow * H + acol, val);
-                            }
-                            st4(trow + acol, val);
-                        }
-                    }
-                } else {
-                    const float capv = (S.mode == 2 && jok) ? S.cap[(size_t)bi * V + j] : 0.f;
-#pragma unroll
-                    for (int k = 0; k < WKA; ++k) {
-                        const int acol = 4 * (ix.g0 + 16 * k);
-                        if (acol < HP) {
-                            f32x4 val = f4zero();
-                            if (jok && acol < H) {
-                                const size_t off = erow * H + acol;
-                                if (S.mode == 0) val = ld4(S.e_in + off);
-                                else {
-                                    val = ld4(&cl[CL_WE][acol]) * capv;
-                                    if (S.e_out != nullptr) st4(S.e_out + off, val);
-                                }
-                            }
-                            st4(trow + acol, val);
-                        }
-                    }
-                }
-            }
-            GCN_STAMP_F(1);
-            ACCF(0);
-            __syncthreads();
-            ACCF(1);
-            GCN_STAMP_F(2);
-            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
-#pragma unroll 1
-                for (int kk = 0; kk < WKB; ++kk) {
-                    constexpr int k = 0;
-                    const int nb = ix.w + 4 * kk;
-                    if (nb < NB) {
-                        const int bcol = 16 * nb + 4 * ix.q;
-                        // epilogue operands are requested before the product so that their latency hides under it
-                        const bool cok = bcol < H;
-                        f32x4 vej[WNS], vnj2[WNS];
-                        const f32x4 base = ld4(a.Ve + (cok ? (size_t)u * H + bcol : 0)) + ld4(a.bU + (cok ? bcol : 0));
-#pragma unroll
-                        for (int s = 0; s < WNS; ++s) {
-                            const int j = (jt + s) * 16 + ix.rs;
-                            const size_t off = (cok && s < ns && j < V) ? ((size_t)(b * V + j) * C + c) * H + bcol : 0;
-                            vej[s] = ld4(a.Ve + off); vnj2[s] = ld4(a.Vn + off);
-                        }
-                        f32x4 et2[WNS];
-#if defined(GCN_ACC_GEMM) && defined(GCN_PHASE_ACC) && GCN_PHASE_ACC == 1
-                        wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2, &pa_[7]);
-#else
-                        wide_gemm_n<GCN_WIDE_PIPE_F>(tile, ns, rW, H, NB, nb, ix.rs, ix.q, et2);
-#endif
-                        if (kk == 0) GCN_STAMP_F(3);
-                        ACCF(2);
-                        f32x4 t1 = f4zero(), t2 = f4zero();
-                        if (cok) {
-#pragma unroll
-                            for (int s = 0; s < WNS; ++s) {
-                                const int j = (jt + s) * 16 + ix.rs;
-                                if (s < ns && j < V) {
-                                    const size_t erow = ((size_t)bi * V + j) * C + c;
-                                    const f32x4 et = et2[s] + base + vej[s];
-                                    const f32x4 vnj = vnj2[s];
-                                    st4(a.e_tmp + erow * H + bcol, et);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const float g = sigmoidf_(et[r]);
-                                        num[k][r] += g * vnj[r];
-                                        den[k][r] += g;
-                                        t1[r] += et[r];
-                                        t2[r] += et[r] * et[r];
-                                    }
-                                }
-                            }
-                        }
-                        wide_acc_cols(ess, bcol, ix.rs == 0 && cok, t1, t2);
-                        ACCF(3);
-                    }
-                    if (kk == 0) GCN_STAMP_F(4);
-                    rot(num); rot(den);
-                }
-            }
-            GCN_STAMP_F(5);
-            ACCF(4);
-            __syncthreads();
-            ACCF(5);
-            GCN_STAMP_F(6);
-#ifdef GCN_PHASE_TRACE
-            ++tstep;
-#endif
-        }
-        // ---- unit end
-#pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            if (nb < NB) {
-                const int bcol = 16 * nb + 4 * ix.q;
-                const f32x4 nm = red16x4(num[k]), dn = red16x4(den[k]);
-                if (ix.rs == 0 && bcol < H) {
-                    f32x4 D = f32x4{1.f, 1.f, 1.f, 1.f}, A = nm;
-                    if (a.mean_agg) {
-                        D = dn + 1e-20f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) A[r] = nm[r] * __builtin_amdgcn_rcpf(D[r]);
-                    }
-                    const f32x4 xt = ld4(a.Ux + (size_t)u * H + bcol) + A;
-                    st4(a.x_tmp + (size_t)u * H + bcol, xt);
-                    st4(a.Aout + (size_t)u * H + bcol, A);
-                    st4(a.Dout + (size_t)u * H + bcol, D);
-                    // this lane is the only one that ever touches these four columns of pxs
-                    st4(&pxs[0][bcol], ld4(&pxs[0][bcol]) + xt);
-                    st4(&pxs[1][bcol], ld4(&pxs[1][bcol]) + xt * xt);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < WKB; ++k) {
-        const int nb = ix.w + 4 * k;
-        if (nb < NB) {
-            const int bcol = 16 * nb + 4 * ix.q;
-            if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
-                float* p = a.partial + (size_t)blockIdx.x * 4 * H;
-                st4(p + bcol, ld4(&ess[0][bcol])); st4(p + H + bcol, ld4(&ess[1][bcol]));
-                st4(p + 2 * H + bcol, ld4(&pxs[0][bcol])); st4(p + 3 * H + bcol, ld4(&pxs[1][bcol]));
-            }
-        }
-    }
-    ACCF(6);
-    ACCF_END(ix.w, ix.lane);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Edge backward (EdgeBwdArgs).  Contiguous ranges of (b, it, jt, c) units, c fastest; a unit walks its rows i WNS at
-// a time (LDS rows 16 s .. 16 s + 15: the 16 columns j of row i + s), so the column partial sums of a thread cover
-// all of them.  The residual-branch term dpre = de * dropout mask is re-read in phase B by the thread that
-// overwrites it instead of being staged through LDS, which leaves room for two workgroups per CU.
-// ------------------------------------------------------------------------------------------------
-#ifndef GCN_WIDE_PIPE_B
-#define GCN_WIDE_PIPE_B 0
-#endif
-__global__ __launch_bounds__(256, 2) void k_edge_bwd_w(EdgeBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float tdet[16 * WNS][WLS];
-    __shared__ __attribute__((aligned(16))) float cc[6][GCN_WIDE_MAX_H];    // constants of the edge BatchNorm backward
-    __shared__ __attribute__((aligned(16))) float qa[WNS][2][GCN_WIDE_MAX_H]; // per row of the step: qi, aggregate A
-    __shared__ __attribute__((aligned(16))) float nss[2][GCN_WIDE_MAX_H];     // BN-backward sums of the layer below over this workgroup's rows
-    const WideIdx ix = wide_idx();
-    const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB;
-    const bool do_next = a.next.tmp != nullptr;
-    const bool mean_agg = a.mean_agg != 0;
-    clds_fill(cc[0], a.stats, H, HP); clds_fill(cc[1], a.stats + H, H, HP);
-    clds_fill(cc[2], a.gamma_e, H, HP); clds_fill(cc[3], a.beta_e, H, HP);
-    clds_fill(cc[4], a.bstats_e, H, HP); clds_fill(cc[5], a.bstats_e + H, H, HP);
-    const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
-    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
-    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
-    const rsrc_t rW = make_rsrc(a.WUt, (uint32_t)H * H * 4);
-    wide_zero_pad(tdet, NB, ix.t);
-    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += 256) (&nss[0][0])[k] = 0.f;
-    const int njt = (V + 15) / 16;
-    const int nit = (V + IT - 1) / IT;
-    const int units = a.B * nit * njt * C;
-    const size_t Rn = (size_t)a.B * V * C;
-    // balanced ranges: every workgroup gets floor or ceil of units / gridDim.x
-    const int u0 = (int)((long long)blockIdx.x * units / (int)gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * units / (int)gridDim.x);
-#ifdef GCN_PHASE_TRACE
-    int tstep = 0;
-#endif
-    __syncthreads();
-    ACCB_DECL;
-    for (int u = u0; u < u1; ++u) {
-        int tt = u;
-        const int c = tt % C; tt /= C;
-        const int jt = tt % njt; tt /= njt;
-        const int it = tt % nit;
-        const int b = tt / nit;
-        const int ja = jt * 16 + ix.arow;
-        const bool jaok = ja < V;
-        const size_t nrow_ja = (size_t)(b * V + min(ja, V - 1)) * C + c;
-        f32x4 cve[WKA], cvn[WKA];
-#pragma unroll
-        for (int k = 0; k < WKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
-        const int i_end = min(V, (it + 1) * IT);
-        for (int i = it * IT; i < i_end; i += WNS) {
-            const int ns = min(WNS, i_end - i);
-            GCN_STAMP_B(0);
-            // Requested before anything else of the step: the Vn row of column j (it serves every row i of the step) and
-            // the two streams of the first row; the streams of the later rows follow when their turn comes.
-            f32x4 vnv[WKA], dnv[WKA], tpv[WKA];
-            auto load_streams = [&](int s) {
-                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
-#pragma unroll
-                for (int k = 0; k < WKA; ++k) {
-                    const int acol = 4 * (ix.g0 + 16 * k);
-                    const size_t off = (jaok && acol < H) ? erow * H + acol : 0;
-                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
-                }
-            };
-#pragma unroll
-            for (int k = 0; k < WKA; ++k) {
-                const int acol = 4 * (ix.g0 + 16 * k);
-                vnv[k] = ld4(a.Vn + ((jaok && acol < H) ? nrow_ja * H + acol : 0));
-            }
-            load_streams(0);
-            // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
-            if (ix.t < WNS * (HP / 4)) {
-                const int s = ix.t / (HP / 4), g = ix.t - s * (HP / 4), acol = 4 * g;
-                f32x4 qv = f4zero(), ai = f4zero();
-                if (s < ns && acol < H) {
-                    const size_t nrow_i = (size_t)(b * V + i + s) * C + c;
-                    const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
-                    f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
-                    f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (dcx.on) dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), g);
-                    const f32x4 xmu = ld4(a.stats + 2 * H + acol), xrs = ld4(a.stats + 3 * H + acol), xga = ld4(a.gamma_x + acol);
-                    const f32x4 xbe = ld4(a.beta_x + acol), xm1 = ld4(a.bstats_x + acol), xm2 = ld4(a.bstats_x + H + acol);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xhx = (xt[r] - xmu[r]) * xrs[r];
-                        const float bnx = xhx * xga[r] + xbe[r];
-                        const float dxd = dxn[r] * dmx[r];
-                        const float dbnx = bnx > 0.f ? dxd : 0.f;
-                        const float dxt = xga[r] * xrs[r] * (dbnx - xm1[r] - xhx * xm2[r]);
-                        qv[r] = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[r]) : dxt;
-                    }
-                }
-                st4(&qa[s][0][acol], qv);
-                st4(&qa[s][1][acol], ai);
-            }
-            ACCB(0);
-            __syncthreads();
-            ACCB(1);
-            GCN_STAMP_B(1);
-            // ---- phase A
-#pragma unroll
-            for (int s = 0; s < WNS; ++s) {
-                if (s >= ns) break;
-                const size_t erow = ((size_t)(b * V + i + s) * V + min(ja, V - 1)) * C + c;
-                float* trow = tdet[16 * s + ix.arow];
-                if (s > 0) load_streams(s);
-                const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
-#pragma unroll
-                for (int k = 0; k < WKA; ++k) {
-                    const int g = ix.g0 + 16 * k;
-                    const int acol = 4 * g;
-                    if (acol < HP) {
-                        f32x4 det = f4zero();
-                        if (jaok && acol < H) {
-                            const f32x4 qv = ld4(&qa[s][0][acol]), ai = ld4(&qa[s][1][acol]);
-                            const f32x4 dn = dnv[k], tp = tpv[k];
-                            const f32x4 vnj = vnv[k];
-                            f32x4 dme = f32x4{1.f, 1.f, 1.f, 1.f};
-                            if (dce.on) dme = drop_mul4(dce, rhe, g);
-                            const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
-                            const f32x4 ebe = ld4(&cc[3][acol]), em1 = ld4(&cc[4][acol]), em2 = ld4(&cc[5][acol]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float qi = qv[r];
-                                const float x = tp[r];
-                                const float xh = (x - emu[r]) * ers[r];
-                                const float bn = xh * ega[r] + ebe[r];
-                                const float d = dn[r] * dme[r];
-                                const float dbn = bn > 0.f ? d : 0.f;
-                                const float gt = sigmoidf_(x);
-                                const float v = ega[r] * ers[r] * (dbn - em1[r] - xh * em2[r]) + qi * (vnj[r] - ai[r]) * gt * (1.f - gt);
-                                det[r] = v;
-                                cve[k][r] += v;
-                                cvn[k][r] += qi * gt;
-                            }
-                            st4(a.det_out + erow * H + acol, det);
-                        }
-                        st4(trow + acol, det);
-                    }
-                }
-            }
-            GCN_STAMP_B(2);
-            ACCB(2);
-            __syncthreads();
-            ACCB(3);
-            GCN_STAMP_B(3);
-            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
-                const int jb = jt * 16 + ix.rs;
-                const bool jbok = jb < V;
-                const size_t erow_b0 = ((size_t)(b * V + i) * V + min(jb, V - 1)) * C + c;
-                const size_t nrow_i0 = (size_t)(b * V + i) * C + c;
-#pragma unroll 1
-                for (int kk = 0; kk < WKB; ++kk) {
-                    const int nb = ix.w + 4 * kk;
-                    if (nb < NB) {
-                        const int bcol = 16 * nb + 4 * ix.q;
-                        const bool valid_b = jbok && bcol < H;
-                        // this thread's elements of de (read here, overwritten below) and of the next layer's pre-BN tensor
-                        f32x4 dold[WNS], ntp[WNS];
-#pragma unroll
-                        for (int s = 0; s < WNS; ++s) {
-                            const size_t off = (valid_b && s < ns) ? (erow_b0 + (size_t)s * V * C) * H + bcol : 0;
-                            dold[s] = ld4(a.de + off);
-                            ntp[s] = do_next ? ld4(a.next.tmp + off) : f4zero();
-                        }
-                        f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
-                        if (do_next) {
-                            const int cb = bcol < H ? bcol : 0;
-                            nmu = ld4(a.next.mean + cb); nrs = ld4(a.next.rstd + cb); nga = ld4(a.next.gamma + cb); nbe = ld4(a.next.beta + cb);
-                        }
-                        f32x4 o2[WNS];
-                        wide_gemm_n<GCN_WIDE_PIPE_B>(tdet, ns, rW, H, NB, nb, ix.rs, ix.q, o2);
-                        if (kk == 0) GCN_STAMP_B(4);
-                        ACCB(4);
-                        f32x4 t1 = f4zero(), t2 = f4zero();
-#pragma unroll
-                        for (int s = 0; s < WNS; ++s) {
-                            if (s >= ns) break;
-                            const size_t erow_b = erow_b0 + (size_t)s * V * C;
-                            f32x4 rsum = ld4(&tdet[16 * s + ix.rs][bcol]);
-                            if (valid_b) {
-                                f32x4 dpre = dold[s];
-                                if (dce.on) dpre *= drop_mul4(dce, drop_rowhash(dce, (uint32_t)erow_b), bcol >> 2);
-                                const f32x4 din = o2[s] + dpre;
-                                st4(a.de + erow_b * H + bcol, din);
-                                if (do_next) {
-                                    f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
-                                    if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)erow_b), bcol >> 2);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const float xh = (ntp[s][r] - nmu[r]) * nrs[r];
-                                        const float bn = xh * nga[r] + nbe[r];
-                                        const float d = bn > 0.f ? din[r] * dm[r] : 0.f;
-                                        t1[r] += d;
-                                        t2[r] += d * xh;
-                                    }
-                                }
-                            }
-                            rsum = red16x4(rsum);
-                            if (ix.rs == 0 && bcol < H) st4(a.rowpart + ((size_t)jt * Rn + nrow_i0 + (size_t)s * C) * H + bcol, rsum);
-                        }
-                        if (do_next) wide_acc_cols(nss, bcol, ix.rs == 0 && bcol < H, t1, t2);
-                        ACCB(5);
-                    }
-                }
-            }
-            GCN_STAMP_B(5);
-            ACCB(6);
-            __syncthreads();
-            ACCB(7);
-            GCN_STAMP_B(6);
-#ifdef GCN_PHASE_TRACE
-            ++tstep;
-#endif
-        }
-        if (jaok) {
-#pragma unroll
-            for (int k = 0; k < WKA; ++k) {
-                const int acol = 4 * (ix.g0 + 16 * k);
-                if (acol < H) {
-                    st4(a.colVe + ((size_t)it * Rn + nrow_ja) * H + acol, cve[k]);
-                    st4(a.colVn + ((size_t)it * Rn + nrow_ja) * H + acol, cvn[k]);
-                }
-            }
-        }
-    }
-    if (do_next) {
-#pragma unroll
-        for (int k = 0; k < WKB; ++k) {
-            const int nb = ix.w + 4 * k;
-            if (nb < NB) {
-                const int bcol = 16 * nb + 4 * ix.q;
-                if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nss[0][bcol]));
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nss[1][bcol]));
-                }
-            }
-        }
-    }
-    ACCB_END(ix.w, ix.lane);
-}
+// The edge kernels of this hidden-size range are in kernels_wide_bf.hpp (products on the bf16 matrix pipe).
 
 // ------------------------------------------------------------------------------------------------
 // Node backward (NodeBwdArgs): one workgroup per 16-row tile (every workgroup of the grid writes a partial row).
