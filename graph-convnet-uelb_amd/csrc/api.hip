@@ -207,8 +207,9 @@ inline int wave_blocks(size_t units, int cap = 512) {
 // ends in a serial stretch of one wavefront, softmax and loss of 16 rows, which more resident workgroups cover:
 // 4.49 -> 3.15 ms at 200 nodes x 100 commodities, 194 -> 140 us for 320 NSFNet graphs, 18.0 -> 16.9 us for 20); the
 // backward kernel (165 registers) and the wide kernels stay at two per CU (no gain from more).
-inline int head_blocks(size_t tiles, bool forward, int H) {
+inline int head_blocks(size_t tiles, bool forward, int H, bool two_blocks = false) {
     int cap = (forward && H <= 64) ? 1024 : 512;
+    if (forward && two_blocks) cap = 1536;        // k_head_fwd4: workgroups of half the size, six per CU (three wavefronts per SIMD)
     if (const char* e = tune_env(forward ? "GCN_TUNE_GRID_H" : "GCN_TUNE_GRID_HB")) cap = std::max(1, std::min(atoi(e), kMaxHeadBlocks));
     return wave_blocks(tiles, cap);
 }
@@ -737,7 +738,7 @@ struct ModelFwdWs {
 ModelFwdWs carve_model_fwd(const ModelPlan& p, Bump& b) {
     ModelFwdWs w;
     w.lw = carve_fwd_ws(p.d, b);
-    w.head_blk = head_blocks((p.d.Re + 15) / 16, true, p.d.H);
+    w.head_blk = head_blocks((p.d.Re + 15) / 16, true, p.d.H, p.d.two_blocks);
     w.loss_partial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * 2);
     w.count_rep = (int*)b.raw((size_t)kCountReps * 2 * p.d.B * p.d.C * sizeof(int));
     const bool deep_wide = p.d.MT > 4 && p.NHID > 1;
@@ -801,11 +802,23 @@ void launch_head_fwd(const ModelPlan& p, const gcn_model_desc* m, const HeadPara
                 k_head_fwd_w<NHID><<<blocks, 256, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
                                                            m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
                                                            m->has_labels ? loss_partial : nullptr, counts, rng, 1000, m->p_mlp, m->training);
-            else
-                k_head_fwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
-                                                                  m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
-                                                                  m->has_labels ? loss_partial : nullptr, counts, count_reps, rng, 1000,
-                                                                  m->p_mlp, m->training);
+            else {
+                bool launched = false;
+                if constexpr (MT == 2 || MT == 4) {
+                    if (p.d.two_blocks) {        // two column blocks per wavefront (from 300,000 edge rows on, as the edge kernels)
+                        k_head_fwd4<MT, NHID><<<blocks, 32 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
+                                                                          m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                                          m->has_labels ? loss_partial : nullptr, counts, count_reps, rng,
+                                                                          1000, m->p_mlp, m->training);
+                        launched = true;
+                    }
+                }
+                if (!launched)
+                    k_head_fwd3<MT, NHID><<<blocks, 64 * MT, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,
+                                                                      m->has_labels ? y_edges : nullptr, edge_cw, y_pred,
+                                                                      m->has_labels ? loss_partial : nullptr, counts, count_reps, rng, 1000,
+                                                                      m->p_mlp, m->training);
+            }
         }
     } else if constexpr (MT != 0)
     k_head_fwd<MT, NHID><<<blocks, GCN_BLOCK, 0, st>>>(p.d.Re, p.d.V, p.d.C, p.d.H, p.voc, hp, src, cap, m->mask_invalid_edges,

@@ -555,3 +555,133 @@ __global__ __launch_bounds__(32 * MT, 2) void k_edge_bwd4(EdgeBwdArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Head forward (edge MLP with at most one hidden layer, loss, edge error) with two column blocks per wavefront: the same
+// outputs, argument list and per-workgroup partial rows as k_head_fwd3 of kernels_strip.hpp, MT / 2 wavefronts per
+// workgroup.  A thread stages rows arow and arow + 8 of its float4 column group; wavefront w multiplies the tile by the
+// weight rows of column blocks w and w + MT / 2 from one LDS read of the operand and finishes eight outputs per lane,
+// so the per-tile bookkeeping (coordinates, barriers, row reductions, the loss of 16 rows) is paid by half as many
+// wavefronts: 3.16 -> 2.81 ms at 200 nodes x 100 commodities on a grid of six workgroups per CU (three wavefronts per
+// SIMD, what its 163 registers allow; larger grids leave a second round of workgroups).  The backward kernel was built
+// the same way and is not here: with both products' weight rows, the fused weight-gradient accumulators and the sums
+// for three outputs per column it needs more than 256 registers per lane (one wavefront per SIMD, 8.9 ms against the
+// 7.2 ms of k_head_bwd3; capped at 256 it spills and is slower still).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NHID>
+__global__ __launch_bounds__(32 * MT) void k_head_fwd4(
+    size_t rows, int V, int C, int H, int voc, HeadParams hp, EdgeSrc src, const float* __restrict__ cap, int mask_invalid,
+    const long long* __restrict__ y_edges, const float* __restrict__ edge_cw, float* __restrict__ logits,
+    float* __restrict__ loss_partial, int* __restrict__ counts, int count_reps, const unsigned long long* __restrict__ rng,
+    int stream_id0, float p, int training) {
+    static_assert(NHID <= 1, "at most one hidden layer");
+    using GM = Strip2Geom<MT>;
+    __shared__ __attribute__((aligned(16))) float tile[2][16][GM::LS];
+    __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GM::HP];
+    __shared__ float red[2][GM::NW][16][2];
+    const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
+    const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;        // rows arow and arow + 8
+    const bool acol_ok = acol < H;
+    int bcol[2];
+    bool bcol_ok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { bcol[k] = 16 * (w + k * GM::NW) + 4 * q; bcol_ok[k] = bcol[k] < H; }
+    edge_src_fill_consts<MT>(cl, src, H);
+    const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
+    const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
+    f32x4 wf0[MT], wf1[MT];
+    if (NHID) { strip_wfrag<MT>(wf0, hp.hidW[0], H, w, rs, q); strip_wfrag<MT>(wf1, hp.hidW[0], H, w + GM::NW, rs, q); }
+    f32x4 b1[2], w0[2], w1[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        b1[k] = (NHID && bcol_ok[k]) ? ld4(hp.hidB[0] + bcol[k]) : f4zero();
+        w0[k] = bcol_ok[k] ? ld4(hp.outW + bcol[k]) : f4zero();
+        w1[k] = (bcol_ok[k] && voc > 1) ? ld4(hp.outW + H + bcol[k]) : f4zero();
+    }
+    const float b2_0 = hp.outB[0], b2_1 = voc > 1 ? hp.outB[1] : 0.f;
+    const float cw0 = edge_cw ? edge_cw[0] : 0.f, cw1 = edge_cw ? edge_cw[1] : 0.f;
+    const size_t ntiles = (rows + 15) / 16;
+    const int BC_stride = V * V * C;
+    float acc_wn = 0.f, acc_w = 0.f;
+    int buf = 0;
+    __syncthreads();
+    HeadRaw raw0 = head_load(src, (size_t)blockIdx.x * 16 + arow, rows, H, C, acol, acol_ok);
+    HeadRaw raw1 = head_load(src, (size_t)blockIdx.x * 16 + arow + 8, rows, H, C, acol, acol_ok);
+    for (size_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        // operands of this tile's epilogue first, then the next tile's input (vector-memory operations retire in issue order)
+        const size_t row = tl * 16 + rs;
+        const size_t rowc = row < rows ? row : rows - 1;
+        const float capv = mask_invalid ? cap[rowc / C] : 1.f;
+        const int yv = y_edges != nullptr ? (int)y_edges[rowc] : 0;
+        {
+            const size_t rowa = tl * 16 + arow;
+            st4(&tile[buf][arow][acol], head_finish<MT>(src, raw0, cl, sdc, rowa, rowa < rows && acol_ok, acol, ag));
+            st4(&tile[buf][arow + 8][acol], head_finish<MT>(src, raw1, cl, sdc, rowa + 8, rowa + 8 < rows && acol_ok, acol, ag));
+            if (tl + gridDim.x < ntiles) {
+                raw0 = head_load(src, (tl + gridDim.x) * 16 + arow, rows, H, C, acol, acol_ok);
+                raw1 = head_load(src, (tl + gridDim.x) * 16 + arow + 8, rows, H, C, acol, acol_ok);
+            }
+        }
+        __syncthreads();
+        f32x4 h[2];
+        if (NHID) {
+            strip_gemm2<MT>(tile[buf], wf0, wf1, rs, q, h[0], h[1]);
+            const uint32_t rh = hdc.on ? drop_rowhash(hdc, (uint32_t)row) : 0u;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                h[k] += b1[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[k][r] = h[k][r] > 0.f ? h[k][r] : 0.f;
+                if (hdc.on) h[k] *= drop_mul4(hdc, rh, bcol[k] >> 2);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) h[k] = ld4(&tile[buf][rs][bcol_ok[k] ? bcol[k] : 0]);
+        }
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p0 += h[k][r] * w0[k][r]; p1 += h[k][r] * w1[k][r]; }
+        p0 = redq(p0); p1 = redq(p1);
+        if (q == 0) { red[buf][w][rs][0] = p0; red[buf][w][rs][1] = p1; }
+        __syncthreads();
+        if (w == 0 && q == 0 && row < rows) {
+            float l0 = b2_0, l1 = b2_1;
+#pragma unroll
+            for (int k = 0; k < GM::NW; ++k) { l0 += red[buf][k][rs][0]; l1 += red[buf][k][rs][1]; }
+            if (mask_invalid && capv == 0.f) { l0 = -1e9f; l1 = -1e9f; }
+            if (voc == 1) {
+                logits[row] = l0;
+            } else {
+                logits[row * 2] = l0;
+                logits[row * 2 + 1] = l1;
+                if (y_edges != nullptr) {
+                    const int y = yv;
+                    const float mx = fmaxf(l0, l1);
+                    const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+                    const float wgt = y ? cw1 : cw0;
+                    acc_wn += -wgt * ((y ? l1 : l0) - lse);
+                    acc_w += wgt;
+                    const int pred = l1 > l0 ? 1 : 0;
+                    if (y + pred > 0 && counts != nullptr) {
+                        const int b = (int)(row / BC_stride), c = (int)(row % C);
+                        const int BC = (int)(rows / BC_stride) * C;
+                        int* cnt = counts + (size_t)(blockIdx.x % count_reps) * 2 * BC;     // this workgroup's replica
+                        atomicAdd(&cnt[BC + b * C + c], 1);
+                        if (pred == y) atomicAdd(&cnt[b * C + c], 1);
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    if (loss_partial != nullptr && w == 0) {
+        acc_wn = red16(acc_wn);      // lanes with q != 0 hold zeros
+        acc_w = red16(acc_w);
+        if (t == 0) {
+            loss_partial[(size_t)blockIdx.x * 2] = acc_wn;
+            loss_partial[(size_t)blockIdx.x * 2 + 1] = acc_w;
+        }
+    }
+}
