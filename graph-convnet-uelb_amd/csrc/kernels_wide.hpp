@@ -288,14 +288,6 @@ __device__ unsigned long long g_phase_acc[1024][12][8];
 #define ACCB(slot) do { } while (0)
 #define ACCB_END(w, lane) do { } while (0)
 #endif
-// phase stamps (GCN_PHASE_TRACE builds): the forward kernel writes the trace unless GCN_TRACE_BWD selects the backward one
-#ifdef GCN_TRACE_BWD
-#define GCN_STAMP_F(slot) do { } while (0)
-#define GCN_STAMP_B(slot) GCN_STAMP(slot)
-#else
-#define GCN_STAMP_F(slot) GCN_STAMP(slot)
-#define GCN_STAMP_B(slot) do { } while (0)
-#endif
 // The edge kernels of this hidden-size range are in kernels_wide_bf.hpp (products on the bf16 matrix pipe).
 
 // ------------------------------------------------------------------------------------------------
