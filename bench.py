@@ -680,9 +680,24 @@ def main():
         tk = time_kernels(eager, lib, [kb, kf], nprof)
         roofline = edge_kernel_roofline(kb, False, tk[kb][0], tk[kb][1], B, V, C, H, plan["two_blocks"])
         roofline_fwd = edge_kernel_roofline(kf, True, tk[kf][0], tk[kf][1], B, V, C, H, plan["two_blocks"])
+        step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
+        roofline["whole_step_algorithmic_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
+        for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore
+            p.grad = gview
+        del eager
         # HBM traffic per launch: measured by counter passes this run starts itself; the committed table of earlier
-        # passes (profiles/pmc_traffic.json, only if taken on these sources) stands in where that is not possible
-        live = {} if (args.skip_traffic or world != 1) else live_traffic(args.config, B, Lr, [kb, kf])
+        # passes (profiles/pmc_traffic.json, only if taken on these sources) stands in where that is not possible.
+        # The child runs need the device memory this process holds for its own steps (the large configurations keep
+        # tens of GB of saved activations per step object): release it first.
+        grad_bytes = int(step.flat_grad.numel()) * 4
+        live = {}
+        if not args.skip_traffic and world == 1:
+            if dist is None and buckets is None:
+                for p in step.params:
+                    p.grad = None
+                step = None                     # (one_step and full_step see the same variable: nothing else holds the object)
+                torch.cuda.empty_cache()
+            live = live_traffic(args.config, B, Lr, [kb, kf])
         for rf, name in ((roofline, kb), (roofline_fwd, kf)):
             if name in live:
                 rf["traffic"] = live[name]
@@ -694,11 +709,6 @@ def main():
                 rf["traffic_source"] = "profiles/pmc_traffic.json (committed counter passes)"
             if rf["traffic"]:
                 rf["traffic_over_algorithmic"] = round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
-        step_bytes = (20.0 * Lr + 20.0) * H * (B * V * V * C)
-        roofline["whole_step_algorithmic_GBps"] = round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1)
-        for p, gview in zip(step.params, step.grad_views):   # the eager helper re-pointed p.grad; restore
-            p.grad = gview
-        del eager
 
     out = None
     if rank == 0:
@@ -715,7 +725,7 @@ def main():
             "rccl_ranks": D.rccl_ranks(),
             "gradient_allreduce": None if dist is None else {
                 "backend": backend, "op": "all_reduce AVG" if backend == "nccl" else "all_reduce SUM, host-staged",
-                "bytes": int(step.flat_grad.numel()) * 4, "per_step": 1,
+                "bytes": grad_bytes, "per_step": 1,
                 # max over ranks: device time between events recorded around the collective on the step's stream, and
                 # host wall time of the same stretch (collective launch to completion), step already finished
                 "ms_per_step": round(allreduce_ms[0], 4), "wall_ms_per_step": round(allreduce_ms[1], 4),
@@ -733,7 +743,7 @@ def main():
             except Exception as ex:      # the headline metric must still be reported
                 out["batch_sweep"] = {"error": repr(ex)}
         if world == 1 and not args.skip_large and args.config == "nsfnet_10_commodities" and not args.batch:
-            del step
+            step = None
             torch.cuda.empty_cache()
             out["large_configs"] = large_configs(device, rank)
         if world == 1 and not args.skip_beam:
