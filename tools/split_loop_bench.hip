@@ -173,6 +173,60 @@ __device__ __forceinline__ void split_gemm_d(const unsigned char* planes, int pl
     }
 }
 
+// NC column blocks at once with the LDS operands of one tile read while the 6 NC MFMAs of the tile before it run (two
+// register sets): the LDS reads of a k block are then 1 / NC of what one block per pass needs, and never waited for.
+// D = 9 selects it.
+template <int NS, int NC, bool ASM = false>
+__device__ __forceinline__ void split_gemm_t(const unsigned char* planes, int plane_bytes, const u32x4* __restrict__ Wt, int NB, int nb,
+                                             int lane, int rs, int q, f32x4 (&o)[NC][NS]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) o[c][s] = f4zero();
+    const size_t pstride = (size_t)NB * SKB * 64;
+    u32x4 w[NC][3], wn[NC][3];
+    auto loadw = [&](u32x4 (&d)[NC][3], int kb) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int nbc = min(nb + 4 * c, NB - 1);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[c][p] = Wt[p * pstride + ((size_t)nbc * SKB + min(kb, SKB - 1)) * 64 + lane];
+        }
+    };
+    auto read_tile = [&](u32x4 (&a)[3], int s, int kb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const u32x4*>(planes + p * plane_bytes + lds_off(16 * s + rs, 4 * min(kb, SKB - 1) + q));
+    };
+    loadw(w, 0);
+    u32x4 a[2][3];
+    read_tile(a[0], 0, 0);
+    static_assert(SKB % 2 == 0, "two k blocks per trip");
+    for (int kb0 = 0; kb0 < SKB; kb0 += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int kb = kb0 + d;
+            loadw(wn, kb + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int cur = (NS * d + s) & 1;
+                if (s + 1 < NS) read_tile(a[cur ^ 1], s + 1, kb);
+                else read_tile(a[cur ^ 1], 0, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#define MM(pw, pa) _Pragma("unroll") for (int c = 0; c < NC; ++c) { \
+        if constexpr (ASM) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[c][s]) : "v"(w[c][pw]), "v"(a[cur][pa])); \
+        else o[c][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[c][pw]), __builtin_bit_cast(bf16x8, a[cur][pa]), o[c][s], 0, 0, 0); }
+                MM(2, 0); MM(0, 2); MM(1, 1); MM(1, 0); MM(0, 1); MM(0, 0);
+#undef MM
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) w[c][p] = wn[c][p];
+        }
+    }
+}
+
 template <int NS, int NC, int D = 1>
 __global__ __launch_bounds__(256) void k_split(const float* __restrict__ X, const u32x4* __restrict__ Wt, float* __restrict__ out, int H,
                                                int iters, int write_out) {
@@ -201,13 +255,15 @@ __global__ __launch_bounds__(256) void k_split(const float* __restrict__ X, cons
 #pragma unroll 1
         for (int nb = ix.w; nb < NB; nb += 4 * NC) {
             f32x4 o[NC][NS];
-            if (NC == 2 && nb + 4 >= NB) {
+            if (NC == 2 && D < 8 && nb + 4 >= NB) {
                 f32x4 o1[1][NS];
                 split_gemm<NS, 1>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o1);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { o[0][s] = o1[0][s]; o[NC - 1][s] = f4zero(); }
             } else {
-                if constexpr (D == 1) split_gemm<NS, NC>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o);
+                if constexpr (D == 9) split_gemm_t<NS, NC>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o);
+                else if constexpr (D == 8) { split_gemm_t<NS, NC, true>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o); asm volatile("s_nop 7\n s_nop 7" ::: "memory"); }
+                else if constexpr (D == 1) split_gemm<NS, NC>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o);
                 else split_gemm_d<NS, NC, D>(dynb, PB, Wt, NB, nb, ix.lane, ix.rs, ix.q, o);
             }
 #pragma unroll
@@ -334,6 +390,15 @@ int main() {
     hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     k_presplit<<<(NB * SKB + 3) / 4, 256>>>(W, Wt, H, NB);
     hipDeviceSynchronize();
+    // tile-pipelined form (ahead=9), one workgroup of four wavefronts per CU = one wavefront per SIMD
+    run_split<4, 1, 9>(X, Wt, out, H, 1, ref);
+    run_split<4, 2, 9>(X, Wt, out, H, 1, ref);
+    run_split<4, 3, 9>(X, Wt, out, H, 1, ref);
+    run_split<4, 5, 9>(X, Wt, out, H, 1, ref);
+    run_split<4, 5, 8>(X, Wt, out, H, 1, ref);
+    run_split<4, 3, 8>(X, Wt, out, H, 1, ref);
+    run_split<4, 2, 8>(X, Wt, out, H, 1, ref);
+    run_split<4, 1, 8>(X, Wt, out, H, 1, ref);
     for (int wpc = 1; wpc <= 2; ++wpc) {
         run_f32<3>(X, W, out, H, wpc, ref);
         run_f32<2>(X, W, out, H, wpc, ref);
