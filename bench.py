@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "graph-convnet-uelb_amd"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (spec)
+COPY_RATE_GBS = 5460.0      # best streaming copy measured on this pool (not a peak: reported beside the roofline only)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA: 256 CUs x 256 flop per cycle x 2.4 GHz
 DOMINANT_KERNEL = "k_edge_bwd"         # k_edge_bwd4 (H of 2 or 4 column blocks), k_edge_bwd3, k_edge_bwd_ws above 64
 
@@ -709,6 +710,11 @@ def main():
                 rf["traffic_source"] = "profiles/pmc_traffic.json (committed counter passes)"
             if rf["traffic"]:
                 rf["traffic_over_algorithmic"] = round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
+                if rf.get("avg_launch_us"):
+                    # the rate the kernel moves its real bytes at, next to what a plain streaming copy reaches on this
+                    # pool's boxes (tools/copy_peak_bench.hip: 5.46 TB/s, profiles/r03_copy_bandwidth.txt)
+                    rf["traffic_GBps"] = round(rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9, 1)
+                    rf["traffic_frac_of_measured_copy_rate"] = round(rf["traffic_GBps"] / COPY_RATE_GBS, 3)
 
     out = None
     if rank == 0:

@@ -210,6 +210,7 @@ inline int wave_blocks(size_t units, int cap = 512) {
 inline int head_blocks(size_t tiles, bool forward, int H, bool two_blocks = false) {
     int cap = (forward && H <= 64) ? 1024 : 512;
     if (forward && two_blocks) cap = 1536;        // k_head_fwd4: workgroups of half the size, six per CU (three wavefronts per SIMD)
+    if (!forward && two_blocks && H <= 64) cap = 768;   // k_head_bwd3 at three wavefronts per SIMD: three workgroups per CU
     if (const char* e = tune_env(forward ? "GCN_TUNE_GRID_H" : "GCN_TUNE_GRID_HB")) cap = std::max(1, std::min(atoi(e), kMaxHeadBlocks));
     return wave_blocks(tiles, cap);
 }
@@ -779,7 +780,7 @@ ModelBwdWs carve_model_bwd(const ModelPlan& p, Bump& b) {
     // before layer L-1 starts); deeper MLPs get NHID contiguous slabs of their own
     w.dpre_stash = p.NHID > 1 ? b.f((size_t)p.NHID * eh) : nullptr;
     w.h_stash = p.NHID > 1 ? b.f((size_t)(p.NHID - 1) * eh) : nullptr;
-    w.head_blk = head_blocks((p.d.Re + 15) / 16, false, p.d.H);
+    w.head_blk = head_blocks((p.d.Re + 15) / 16, false, p.d.H, p.d.two_blocks);
     w.wpartial = b.f((size_t)w.head_blk * GCN_WAVES_PER_BLOCK * (size_t)((p.voc * p.d.H + p.voc + 3) & ~3));
     w.S_h = tn_slices(p.d.Re, p.d.H);
     w.tn_h = b.f((size_t)std::max(w.S_h, w.head_fused ? w.head_blk : 0) * std::max(1, p.NHID) * ((size_t)p.d.H * p.d.H + p.d.H));

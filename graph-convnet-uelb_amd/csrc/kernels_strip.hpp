@@ -39,6 +39,25 @@ __device__ __forceinline__ f32x4 strip_gemm(const float (*tile)[StripGeom<MT>::L
     return acc0 + acc1;
 }
 
+// The same product with the weight fragments of this lane in LDS (wl[s * 64], read inside the loop: 4 MT registers
+// less than fragments held for the whole kernel, which is what decides between two and three wavefronts per SIMD in
+// the head backward kernel).
+template <int MT>
+__device__ __forceinline__ f32x4 strip_gemm_lw(const float (*tile)[StripGeom<MT>::LS], const f32x4* __restrict__ wl, int rs, int q) {
+    f32x4 acc0 = f4zero(), acc1 = f4zero();
+#pragma unroll
+    for (int s = 0; s < MT; ++s) {
+        const f32x4 in = *reinterpret_cast<const f32x4*>(&tile[rs][16 * s + 4 * q]);
+        const f32x4 wf = wl[s * 64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((t & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], in[t], acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], in[t], acc1, 0, 0, 0);
+        }
+    }
+    return acc0 + acc1;
+}
+
 // weight rows 16w + rs of W ([H][H] row-major), columns 16s + 4q ..: the A operand of column block w
 template <int MT>
 __device__ __forceinline__ void strip_wfrag(f32x4 (&wf)[MT], const float* __restrict__ W, int H, int w, int rs, int q) {
@@ -1022,7 +1041,7 @@ __global__ __launch_bounds__(64 * MT) void k_head_fwd3(
 // dpre^T e (one H x H + H slab per workgroup, rows = output channels, then the bias sums) from the two tiles it has in
 // LDS anyway; the caller then passes null stashes and neither the head's input nor dpre goes to memory.
 template <int MT, int NHID>
-__global__ __launch_bounds__(64 * MT) void k_head_bwd3(
+__global__ __launch_bounds__(64 * MT, 3) void k_head_bwd3(
     size_t rows, int V, int C, int H, int voc, HeadParams hp, const float* __restrict__ hidWt, EdgeSrc src, NextBn next,
     float* __restrict__ e_stash, const float* __restrict__ cap, int mask_invalid, const long long* __restrict__ y_edges,
     const float* __restrict__ edge_cw, const float* __restrict__ loss_out, const float* __restrict__ dloss,
@@ -1035,6 +1054,7 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     __shared__ __attribute__((aligned(16))) float tdp[2][16][GM::LS];
     __shared__ __attribute__((aligned(16))) float cl[CL_ROWS][GM::HP];
     __shared__ float red[2][MT][16][2];
+    __shared__ __attribute__((aligned(16))) f32x4 wtl[NHID ? MT * MT * 64 : 1];   // fragments of the transposed hidden weight, [wavefront][s][lane]
     zero_fill(z);
     const int t = threadIdx.x, lane = t & 63, rs = lane & 15, q = lane >> 4, w = t >> 6;
     const int arow = t / GM::G, ag = t - arow * GM::G, acol = 4 * ag;
@@ -1045,8 +1065,14 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
     const DropCfg sdc = drop_cfg(rng, src.drop_sid, src.drop_p, src.drop_on && src.mode == 1);
     const DropCfg hdc = drop_cfg(rng, stream_id0, p, training);
     const bool do_next = next.tmp != nullptr;
-    f32x4 wf[MT], wft[MT];
-    if (NHID) { strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q); strip_wfrag_t<MT>(wft, hp.hidW[0], H, w, rs, q); }
+    f32x4 wf[MT];
+    if (NHID) {
+        f32x4 wft[MT];
+        strip_wfrag_t<MT>(wft, hp.hidW[0], H, w, rs, q);
+#pragma unroll
+        for (int s = 0; s < MT; ++s) wtl[(w * MT + s) * 64 + lane] = wft[s];
+        strip_wfrag<MT>(wf, hp.hidW[0], H, w, rs, q);
+    }
     const f32x4 b1 = (NHID && bcol_ok) ? ld4(hp.hidB[0] + bcol) : f4zero();
     const f32x4 w0 = bcol_ok ? ld4(hp.outW + bcol) : f4zero();
     const f32x4 w1 = (bcol_ok && voc > 1) ? ld4(hp.outW + H + bcol) : f4zero();
@@ -1139,7 +1165,7 @@ __global__ __launch_bounds__(64 * MT) void k_head_bwd3(
         if (NHID) {
             st4(&tdp[buf][rs][bcol], dp);
             __syncthreads();
-            dv = strip_gemm<MT>(tdp[buf], wft, rs, q);
+            dv = strip_gemm_lw<MT>(tdp[buf], wtl + w * MT * 64 + lane + lds_opaque_zero(), rs, q);
             if (fuse) {
                 // dW[n][kc] += sum over the tile's rows of dpre[row][n] * e[row][kc] (A[i = n][kk = row], B[kk = row][j = kc]);
                 // rows beyond the tensor hold zeros in both tiles
