@@ -11,7 +11,7 @@ step() { echo "== $*"; }
 for spec in nsfnet_10_commodities:20:50 nsfnet_20_commodities:10:30 default2:10:30 synthetic_200n_100c:2:5 synthetic_100n_50c_h300_l30:2:3; do
   cfg=${spec%%:*}; rest=${spec#*:}; tsteps=${rest%%:*}; bsteps=${rest#*:}
   step "kernel trace $cfg"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$cfg -- python3 bench.py --config $cfg --steps $tsteps --warmup 2 --skip-cpu --skip-beam --skip-sweep --skip-opt --no-graph > $out/prof_$cfg.log 2>&1 || { echo "trace failed"; tail -5 $out/prof_$cfg.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$cfg -- python3 bench.py --config $cfg --steps $tsteps --warmup 2 --skip-cpu --skip-beam --skip-sweep --skip-opt --skip-large --skip-traffic --no-graph > $out/prof_$cfg.log 2>&1 || { echo "trace failed"; tail -5 $out/prof_$cfg.log; exit 1; }
   cp $(ls $out/prof_$cfg/*/*kernel_stats.csv | head -1) $out/kernel_stats_${cfg}_eager.csv
   step "bench $cfg"
   timeout -k 10 300 python -u bench.py --config $cfg --steps $bsteps --warmup 5 --skip-cpu --skip-beam --skip-sweep --skip-large > $out/bench_$cfg.log 2>&1 || { echo "bench failed"; tail -5 $out/bench_$cfg.log; exit 1; }
