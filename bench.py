@@ -146,7 +146,8 @@ def cpu_baseline(shape, batch):
     """fwd+bwd of the CPU oracle on the same batch, in the two modes and at the two thread counts that matter:
     train mode (dropout on: what the trainer runs; more than half of the reference's CPU step is the dropout mask
     generator) and eval mode with gradients (dropout off: the parity mode), each with all host threads torch uses and
-    with one thread.  A bounded sample: about 25 s of CPU work in all."""
+    with one thread, plus the train mode with autograd's anomaly detection on as the reference's trainer runs it.  A
+    bounded sample: about 30 s of CPU work in all."""
     from oracle import gcn_oracle
     from src.gcn.models.gcn_model import ResidualGatedGCNModel
     cfg = Cfg(num_nodes=shape["V"], num_commodities=shape["C"], voc_edges_in=3, voc_edges_out=2,
@@ -167,8 +168,9 @@ def cpu_baseline(shape, batch):
         _, loss = gcn_oracle.model_forward(P, ocfg, cap, comm, x_nodes, y_edges, batch["edge_cw"], training=training)
         loss.backward()
 
-    def timed(training, threads, budget_s, max_steps):
+    def timed(training, threads, budget_s, max_steps, anomaly=False):
         torch.set_num_threads(threads)
+        torch.autograd.set_detect_anomaly(anomaly)
         try:
             one(training)                             # warm-up
             times = []
@@ -179,6 +181,7 @@ def cpu_baseline(shape, batch):
                 times.append(time.time() - t0)
         finally:
             torch.set_num_threads(all_threads)
+            torch.autograd.set_detect_anomaly(False)
         med = float(np.median(times))
         return {"graphs_per_s": round(shape["B"] / med, 3), "ms_per_step": round(med * 1e3, 2), "threads": threads,
                 "steps_timed": len(times)}
@@ -186,6 +189,8 @@ def cpu_baseline(shape, batch):
     modes = {
         "train_all_threads": timed(True, all_threads, 8.0, 40),
         "eval_grad_all_threads": timed(False, all_threads, 5.0, 40),
+        # the reference's trainer leaves autograd's anomaly detection on for every step (src/gcn/train/trainer.py:100)
+        "train_all_threads_anomaly_detection": timed(True, all_threads, 4.0, 20, anomaly=True),
         "train_1_thread": timed(True, 1, 4.0, 10),
         "eval_grad_1_thread": timed(False, 1, 4.0, 10),
     }
