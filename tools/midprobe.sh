@@ -7,7 +7,7 @@ cfg=$1; shift
 for m in "$@"; do
   export GCN_TUNE_MIDPROBE=$m
   rm -rf gpurun_out/prof_mid_$m
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mid_$m -- python3 bench.py --config $cfg --steps 10 --warmup 3 --skip-cpu --skip-beam --skip-sweep --skip-opt --no-graph > gpurun_out/prof_mid_$m.log 2>&1 || { echo "failed $m"; tail -3 gpurun_out/prof_mid_$m.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mid_$m -- python3 bench.py --config $cfg --steps 10 --warmup 3 --skip-cpu --skip-beam --skip-sweep --skip-opt --skip-large --skip-traffic --no-graph > gpurun_out/prof_mid_$m.log 2>&1 || { echo "failed $m"; tail -3 gpurun_out/prof_mid_$m.log; exit 1; }
   f=$(find gpurun_out/prof_mid_$m -name "*kernel_stats.csv" | head -1)
   python3 - "$f" $m <<'PY'
 import csv,sys
