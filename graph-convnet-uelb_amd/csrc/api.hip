@@ -509,8 +509,25 @@ int launch_edge_bwd(const Dims& d, int agg, float p, int training, const unsigne
     const int blocks = edge_bwd_blocks(d);
     if constexpr (MT == 0) {
         a.WUs = W.wsplit;
-        if (int rc = reserve_split_lds(k_edge_bwd_ws, "k_edge_bwd_ws")) return rc;
-        GCN_LAUNCH_TIMED_LDS("k_edge_bwd_ws", k_edge_bwd_ws, blocks, STH, 3 * SPB, a);
+        // a last column tile with at most 8 of its 16 columns in use goes to the kernel that packs several rows i into a tile
+        const int njt = (d.V + 15) / 16, vlast = d.V - 16 * (njt - 1);
+        const bool packed_last = vlast <= 8;
+        int blocks_main = 0, blocks_last = 0;
+        if (!packed_last || njt > 1) {
+            a.jt_lo = 0; a.jt_n = packed_last ? njt - 1 : njt; a.part_off = 0;
+            blocks_main = range_blocks((size_t)d.B * d.nit * a.jt_n * d.C, d.grid_b);
+            if (const char* e = tune_env("GCN_TUNE_GRID_B")) blocks_main = range_blocks((size_t)d.B * d.nit * a.jt_n * d.C, std::min(atoi(e), kMaxPartBlocks / 2));
+            if (int rc = reserve_split_lds(k_edge_bwd_ws, "k_edge_bwd_ws")) return rc;
+            GCN_LAUNCH_TIMED_LDS("k_edge_bwd_ws", k_edge_bwd_ws, blocks_main, STH, 3 * SPB, a);
+        }
+        if (packed_last) {
+            a.jt_lo = njt - 1; a.jt_n = 1; a.part_off = blocks_main;
+            blocks_last = range_blocks((size_t)d.B * d.nit * d.C, d.grid_b);
+            if (int rc = reserve_split_lds(k_edge_bwd_wp, "k_edge_bwd_wp")) return rc;
+            GCN_LAUNCH_TIMED_LDS("k_edge_bwd_wp", k_edge_bwd_wp, blocks_last, STH, 3 * SPB, a);
+        }
+        if (nx.on) npart_e = blocks_main + blocks_last;
+        return 0;
     } else {
         bool launched = false;
         if constexpr (MT == 2 || MT == 4) {

@@ -204,6 +204,8 @@ struct EdgeBwdArgs {
     NextBn next;
     const float* e_in;       // strip kernel: the layer's edge input (operand of the fused weight-gradient product)
     float* wg_out;           // strip kernel: [gridDim.x][H*H + H] partial d edge_feat.U.weight / .bias
+    int jt_lo, jt_n;         // wide kernels: column tiles of this launch (k_edge_bwd_ws / k_edge_bwd_wp share the work of a layer)
+    int part_off;            // wide kernels: first row of next.partial this launch writes
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(STH) void k_edge_bwd_ws(EdgeBwdArgs a) {
     const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
     split_zero_planes(planes, ix.t);
     for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += STH) (&nss[0][0])[k] = 0.f;
-    const int njt = (V + 15) / 16;
+    const int njt = a.jt_n;                            // column tiles jt_lo .. jt_lo + jt_n - 1 (the ragged last one may go to k_edge_bwd_wp)
     const int nit = (V + IT - 1) / IT;
     const int units = a.B * nit * njt * C;
     const size_t Rn = (size_t)a.B * V * C;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(STH) void k_edge_bwd_ws(EdgeBwdArgs a) {
     for (int u = u0; u < u1; ++u) {
         int tt = u;
         const int c = tt % C; tt /= C;
-        const int jt = tt % njt; tt /= njt;
+        const int jt = a.jt_lo + tt % njt; tt /= njt;
         const int it = tt % nit;
         const int b = tt / nit;
         const int ja = jt * 16 + ix.arow;
@@ -662,8 +662,290 @@ __global__ __launch_bounds__(STH) void k_edge_bwd_ws(EdgeBwdArgs a) {
             if (nb < NB) {
                 const int bcol = 16 * nb + 4 * ix.q;
                 if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + bcol, ld4(&nss[0][bcol]));
-                    st4(a.next.partial + (size_t)blockIdx.x * 2 * H + H + bcol, ld4(&nss[1][bcol]));
+                    st4(a.next.partial + (size_t)(a.part_off + blockIdx.x) * 2 * H + bcol, ld4(&nss[0][bcol]));
+                    st4(a.next.partial + (size_t)(a.part_off + blockIdx.x) * 2 * H + H + bcol, ld4(&nss[1][bcol]));
+                }
+            }
+        }
+    }
+    ACCB_END(ix.w, ix.lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edge backward of the ragged last column tile (EdgeBwdArgs with jt_lo = that tile, jt_n = 1; same math and outputs as
+// k_edge_bwd_ws for its units (b, it, jt_lo, c)).  When the node count is no multiple of 16 and the last tile has at
+// most 8 of its 16 columns j in use, a 16-row tile in LDS holds P rows i of 16 / P columns each (P = 2, or 4 with at
+// most 4 columns) and a step takes BQR rows i: at 100 nodes the seventh column tile has 4 columns, and walked like the
+// others it costs a seventh of the kernel's time for 4 % of its rows (2.85 ms per launch against 2.48 at 96 nodes per
+// million rows).  A kernel of its own so that the layout arithmetic does not cost the main kernel registers.
+// Dynamic LDS: 3 SPB bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int BQR = 8;          // rows i per step of a packed (P > 1) unit = rows of node-side terms kept in LDS
+// sum over the 16 / P lanes of a tile that belong to the same row i (every lane receives its group's sum); P = 2, 4.
+// Cross-lane moves through the LDS crossbar: packed tiles are the exception, and the order of the additions is fixed.
+__device__ __forceinline__ f32x4 red_group4(f32x4 v, int P) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float y = v[r];
+        y += __shfl_xor(y, 1, 64);
+        y += __shfl_xor(y, 2, 64);
+        if (P == 2) y += __shfl_xor(y, 4, 64);
+        v[r] = y;
+    }
+    return v;
+}
+__global__ __launch_bounds__(STH) void k_edge_bwd_wp(EdgeBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char planes[];
+    __shared__ __attribute__((aligned(16))) float cc[6][GCN_WIDE_MAX_H];    // constants of the edge BatchNorm backward
+    __shared__ __attribute__((aligned(16))) float qa[BQR][2][GCN_WIDE_MAX_H]; // per row i of the step: qi, aggregate A
+    __shared__ __attribute__((aligned(16))) float nss[2][GCN_WIDE_MAX_H];     // BN-backward sums of the layer below over this workgroup's rows
+    const SplitIdx ix = split_idx();
+    const int H = a.H, V = a.V, C = a.C, IT = a.IT, NB = (H + 15) / 16, HP = 16 * NB, NKB = split_nkb(H);
+    const bool do_next = a.next.tmp != nullptr;
+    const bool mean_agg = a.mean_agg != 0;
+    clds_fill(cc[0], a.stats, H, HP); clds_fill(cc[1], a.stats + H, H, HP);
+    clds_fill(cc[2], a.gamma_e, H, HP); clds_fill(cc[3], a.beta_e, H, HP);
+    clds_fill(cc[4], a.bstats_e, H, HP); clds_fill(cc[5], a.bstats_e + H, H, HP);
+    const DropCfg dce = drop_cfg(a.rng, a.sid_e, a.p, a.training);
+    const DropCfg dcx = drop_cfg(a.rng, a.sid_x, a.p, a.training);
+    const DropCfg ndc = drop_cfg(a.rng, a.next.drop_sid, a.p, a.training && do_next);
+    split_zero_planes(planes, ix.t);
+    for (int k = ix.t; k < 2 * GCN_WIDE_MAX_H; k += STH) (&nss[0][0])[k] = 0.f;
+    const int nit = (V + IT - 1) / IT;
+    const size_t Rn = (size_t)a.B * V * C;
+    // all units of this launch are of column tile jt_lo: balanced ranges
+    const int units = a.B * nit * C;
+    const int u0 = (int)((long long)blockIdx.x * units / (int)gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * units / (int)gridDim.x);
+    __syncthreads();
+    ACCB_DECL;
+    const int jt = a.jt_lo;
+    const int vj = min(16, V - 16 * jt);
+    const int lg = vj <= 4 ? 2 : 3, JW = 1 << lg, P = 16 >> lg;                          // columns j per tile row group, rows i per tile
+    const int srows = BQR;                                                                  // rows i per step
+    for (int u = u0; u < u1; ++u) {
+        int tt = u;
+        const int c = tt % C; tt /= C;
+        const int it = tt % nit;
+        const int b = tt / nit;
+        const int adi = ix.arow >> lg, adj = ix.arow & (JW - 1);                            // staging thread: row i and column j inside a tile
+        const int ja = jt * 16 + adj;
+        const bool jaok = ja < V;
+        const size_t nrow_ja = (size_t)(b * V + min(ja, V - 1)) * C + c;
+        f32x4 cve[SKA], cvn[SKA];
+#pragma unroll
+        for (int k = 0; k < SKA; ++k) { cve[k] = f4zero(); cvn[k] = f4zero(); }
+        const int i_end = min(V, (it + 1) * IT);
+        for (int i = it * IT; i < i_end; i += srows) {
+            const int rows = min(srows, i_end - i);
+            const int ns = (rows + P - 1) >> (4 - lg);                                      // tiles in use
+            // Requested before anything else of the step: the Vn row of column j (it serves every row i of the step) and
+            // the two streams of the first tile; the streams of the later tiles follow when their turn comes.
+            f32x4 vnv[SKA], dnv[SKA], tpv[SKA];
+            auto load_streams = [&](int s) {
+                const int r = s * P + adi;
+                const bool ok = jaok && r < rows;
+                const size_t erow = ((size_t)(b * V + i + min(r, rows - 1)) * V + min(ja, V - 1)) * C + c;
+#pragma unroll
+                for (int k = 0; k < SKA; ++k) {
+                    const int acol = 4 * (ix.g0 + 32 * k);
+                    const size_t off = (ok && acol < H) ? erow * H + acol : 0;
+                    dnv[k] = ld4(a.de + off); tpv[k] = ld4(a.e_tmp + off);
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < SKA; ++k) {
+                const int acol = 4 * (ix.g0 + 32 * k);
+                vnv[k] = ld4(a.Vn + ((jaok && acol < H) ? nrow_ja * H + acol : 0));
+            }
+            load_streams(0);
+            // ---- node side of the step, once per (row i, column): qi = d x_tmp / D and the aggregate A of row i
+            for (int e = ix.t; e < srows * (HP / 4); e += STH) {
+                const int r = e / (HP / 4), g = e - r * (HP / 4), acol = 4 * g;
+                f32x4 qv = f4zero(), ai = f4zero();
+                if (r < rows && acol < H) {
+                    const size_t nrow_i = (size_t)(b * V + i + r) * C + c;
+                    const f32x4 dxn = ld4(a.dx + nrow_i * H + acol), xt = ld4(a.x_tmp + nrow_i * H + acol);
+                    f32x4 Dv = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (mean_agg) { Dv = ld4(a.Dn + nrow_i * H + acol); ai = ld4(a.Aagg + nrow_i * H + acol); }
+                    f32x4 dmx = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (dcx.on) dmx = drop_mul4(dcx, drop_rowhash(dcx, (uint32_t)nrow_i), g);
+                    const f32x4 xmu = ld4(a.stats + 2 * H + acol), xrs = ld4(a.stats + 3 * H + acol), xga = ld4(a.gamma_x + acol);
+                    const f32x4 xbe = ld4(a.beta_x + acol), xm1 = ld4(a.bstats_x + acol), xm2 = ld4(a.bstats_x + H + acol);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float xhx = (xt[rr] - xmu[rr]) * xrs[rr];
+                        const float bnx = xhx * xga[rr] + xbe[rr];
+                        const float dxd = dxn[rr] * dmx[rr];
+                        const float dbnx = bnx > 0.f ? dxd : 0.f;
+                        const float dxt = xga[rr] * xrs[rr] * (dbnx - xm1[rr] - xhx * xm2[rr]);
+                        qv[rr] = mean_agg ? dxt * __builtin_amdgcn_rcpf(Dv[rr]) : dxt;
+                    }
+                }
+                st4(&qa[r][0][acol], qv);
+                st4(&qa[r][1][acol], ai);
+            }
+            ACCB(0);
+            __syncthreads();
+            ACCB(1);
+            // ---- phase A
+#pragma unroll
+            for (int s = 0; s < SNS; ++s) {
+                if (s >= ns) break;
+                const int r = s * P + adi;
+                const bool rok = jaok && r < rows;
+                const int rq = min(r, BQR - 1);
+                const size_t erow = ((size_t)(b * V + i + min(r, rows - 1)) * V + min(ja, V - 1)) * C + c;
+                const int lrow = 16 * s + ix.arow;
+                if (s > 0) load_streams(s);
+                const uint32_t rhe = dce.on ? drop_rowhash(dce, (uint32_t)erow) : 0u;
+#pragma unroll
+                for (int k = 0; k < SKA; ++k) {
+                    const int g = ix.g0 + 32 * k;
+                    const int acol = 4 * g;
+                    if (acol < HP) {
+                        f32x4 det = f4zero();
+                        if (rok && acol < H) {
+                            const f32x4 qv = ld4(&qa[rq][0][acol]), ai = ld4(&qa[rq][1][acol]);
+                            const f32x4 dn = dnv[k], tp = tpv[k];
+                            const f32x4 vnj = vnv[k];
+                            f32x4 dme = f32x4{1.f, 1.f, 1.f, 1.f};
+                            if (dce.on) dme = drop_mul4(dce, rhe, g);
+                            const f32x4 emu = ld4(&cc[0][acol]), ers = ld4(&cc[1][acol]), ega = ld4(&cc[2][acol]);
+                            const f32x4 ebe = ld4(&cc[3][acol]), em1 = ld4(&cc[4][acol]), em2 = ld4(&cc[5][acol]);
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) {
+                                const float qi = qv[rr];
+                                const float x = tp[rr];
+                                const float xh = (x - emu[rr]) * ers[rr];
+                                const float bn = xh * ega[rr] + ebe[rr];
+                                const float d = dn[rr] * dme[rr];
+                                const float dbn = bn > 0.f ? d : 0.f;
+                                const float gt = sigmoidf_(x);
+                                const float v = ega[rr] * ers[rr] * (dbn - em1[rr] - xh * em2[rr]) + qi * (vnj[rr] - ai[rr]) * gt * (1.f - gt);
+                                det[rr] = v;
+                                cve[k][rr] += v;
+                                cvn[k][rr] += qi * gt;
+                            }
+                            st4(a.det_out + erow * H + acol, det);
+                        }
+                        split_put4(planes, lrow, g, det);
+                    }
+                }
+            }
+            ACCB(2);
+            __syncthreads();
+            ACCB(3);
+            {   // ---- phase B.  One copy of the product loop: the per-block accumulators rotate through slot 0.
+                const int bdi = ix.rs >> lg, bdj = ix.rs & (JW - 1);                        // this lane's row i and column j inside a tile
+                const int jb = jt * 16 + bdj;
+                const bool jbok = jb < V;
+                const size_t ecol_b = (size_t)min(jb, V - 1) * C + c;
+#pragma unroll 1
+                for (int kk = 0; kk < SKB8; ++kk) {
+                    const int nb = ix.w + 8 * kk;
+                    if (nb < NB) {
+                        const int bcol = 16 * nb + 4 * ix.q;
+                        const bool valid_b = jbok && bcol < H;
+                        // this thread's elements of de (read here, overwritten below) and of the next layer's pre-BN tensor
+                        f32x4 dold[SNS], ntp[SNS];
+#pragma unroll
+                        for (int s = 0; s < SNS; ++s) {
+                            const int r = s * P + bdi;
+                            const size_t off = (valid_b && r < rows) ? ((size_t)(b * V + i + r) * V * C + ecol_b) * H + bcol : 0;
+                            dold[s] = ld4(a.de + off);
+                            ntp[s] = do_next ? ld4(a.next.tmp + off) : f4zero();
+                        }
+                        f32x4 nmu = f4zero(), nrs = f4zero(), nga = f4zero(), nbe = f4zero();
+                        if (do_next) {
+                            const int cb = bcol < H ? bcol : 0;
+                            nmu = ld4(a.next.mean + cb); nrs = ld4(a.next.rstd + cb); nga = ld4(a.next.gamma + cb); nbe = ld4(a.next.beta + cb);
+                        }
+                        f32x4 o2[SNS];
+                        split_gemm_n(planes, ns, a.WUs, NB, NKB, nb, ix.lane, ix.rs, ix.q, o2);
+                        ACCB(4);
+                        f32x4 t1 = f4zero(), t2 = f4zero();
+#pragma unroll
+                        for (int s = 0; s < SNS; ++s) {
+                            if (s >= ns) break;
+                            const int r = s * P + bdi;
+                            const bool rok = r < rows;
+                            const size_t erow_b = (size_t)(b * V + i + min(r, rows - 1)) * V * C + ecol_b;
+                            f32x4 rsum = split_get4(planes, 16 * s + ix.rs, bcol >> 2);
+                            if (valid_b && rok) {
+                                f32x4 dpre = dold[s];
+                                if (dce.on) dpre *= drop_mul4(dce, drop_rowhash(dce, (uint32_t)erow_b), bcol >> 2);
+                                const f32x4 din = o2[s] + dpre;
+                                st4(a.de + erow_b * H + bcol, din);
+                                if (do_next) {
+                                    f32x4 dm = f32x4{1.f, 1.f, 1.f, 1.f};
+                                    if (ndc.on) dm = drop_mul4(ndc, drop_rowhash(ndc, (uint32_t)erow_b), bcol >> 2);
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) {
+                                        const float xh = (ntp[s][rr] - nmu[rr]) * nrs[rr];
+                                        const float bn = xh * nga[rr] + nbe[rr];
+                                        const float d = bn > 0.f ? din[rr] * dm[rr] : 0.f;
+                                        t1[rr] += d;
+                                        t2[rr] += d * xh;
+                                    }
+                                }
+                            }
+                            // sum over the columns j of row i (rows and columns outside the tensor hold zeros in the tile)
+                            rsum = red_group4(rsum, P);
+                            if (bdj == 0 && rok && bcol < H)
+                                st4(a.rowpart + ((size_t)jt * Rn + (size_t)(b * V + i + r) * C + c) * H + bcol, rsum);
+                        }
+                        if (do_next) wide_acc_cols(nss, bcol, ix.rs == 0 && bcol < H, t1, t2);
+                        ACCB(5);
+                    }
+                }
+            }
+            ACCB(6);
+            __syncthreads();
+            ACCB(7);
+        }
+        {
+            // packed tiles: the P staging threads of a column j (one per row group) add their sums up through LDS, in the
+            // order of the row groups (the planes are free between units; plane 0 is cleared again afterwards, its padding
+            // columns have to read as zeros)
+            float* scr = reinterpret_cast<float*>(planes);                                  // [16 tile rows][2][GCN_WIDE_MAX_H]
+#pragma unroll
+            for (int k = 0; k < SKA; ++k) {
+                const int acol = 4 * (ix.g0 + 32 * k);
+                if (acol < HP) {
+                    st4(scr + (size_t)(ix.arow * 2 + 0) * GCN_WIDE_MAX_H + acol, cve[k]);
+                    st4(scr + (size_t)(ix.arow * 2 + 1) * GCN_WIDE_MAX_H + acol, cvn[k]);
+                }
+            }
+            __syncthreads();
+            if (adi == 0 && jaok) {
+#pragma unroll
+                for (int k = 0; k < SKA; ++k) {
+                    const int acol = 4 * (ix.g0 + 32 * k);
+                    if (acol < H) {
+                        f32x4 se = cve[k], sn = cvn[k];
+                        for (int d = 1; d < P; ++d) {
+                            se += ld4(scr + (size_t)((d * JW + adj) * 2 + 0) * GCN_WIDE_MAX_H + acol);
+                            sn += ld4(scr + (size_t)((d * JW + adj) * 2 + 1) * GCN_WIDE_MAX_H + acol);
+                        }
+                        st4(a.colVe + ((size_t)it * Rn + nrow_ja) * H + acol, se);
+                        st4(a.colVn + ((size_t)it * Rn + nrow_ja) * H + acol, sn);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = ix.t * 16; e < 16 * 2 * GCN_WIDE_MAX_H * 4; e += STH * 16) *reinterpret_cast<u32x4*>(planes + e) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+    }
+    if (do_next) {
+#pragma unroll
+        for (int k = 0; k < SKB8; ++k) {
+            const int nb = ix.w + 8 * k;
+            if (nb < NB) {
+                const int bcol = 16 * nb + 4 * ix.q;
+                if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
+                    st4(a.next.partial + (size_t)(a.part_off + blockIdx.x) * 2 * H + bcol, ld4(&nss[0][bcol]));
+                    st4(a.next.partial + (size_t)(a.part_off + blockIdx.x) * 2 * H + H + bcol, ld4(&nss[1][bcol]));
                 }
             }
         }
