@@ -272,16 +272,17 @@ def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
 
 
 @pytest.mark.parametrize("B,V,C,H,agg,chunk,nchunks", [
-    (1, 18, 44, 128, "mean", 2, 9),      # chunks of two rows: half a step each
-    (1, 18, 72, 128, "sum", 3, 6),       # chunks of three rows: every step has one row missing
-    (1, 19, 110, 80, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 3 rows: whole steps, the last one with a row missing
-    (1, 40, 40, 80, "sum", 8, 5),        # five chunks of 8 = two whole steps each, three j tiles
-    (4, 7, 256, 80, "mean", 7, 1),       # one chunk for the whole graph: 4 + 3
-    (1, 22, 300, 80, "mean", 12, 2),     # 12 + 10 rows: 4 + 4 + 4 and 4 + 4 + 2, a ragged second j tile
+    (1, 18, 44, 128, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 2 rows: whole steps and a last chunk of half a step
+    (1, 18, 72, 128, "sum", 8, 3),       # 8 + 8 + 2 rows
+    (1, 19, 110, 80, "mean", 12, 2),     # 12 + 7 rows: the last chunk is 4 + 3, a step with one row missing
+    (1, 17, 200, 80, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 1 rows: a last chunk of a single row
+    (1, 40, 40, 80, "sum", 16, 3),       # 16 + 16 + 8 rows: whole steps, three j tiles (the last one half full: packed tiles)
+    (4, 7, 256, 80, "mean", 7, 1),       # one chunk for the whole graph: 4 + 3 (a single, packed column tile)
+    (1, 22, 300, 80, "mean", 8, 3),      # 8 + 8 + 6 rows, a ragged second j tile of 6 columns (two rows i per tile)
 ])
 def test_wide_layer_row_chunks(B, V, C, H, agg, chunk, nchunks):
-    """The backward edge kernel walks the rows i of a chunk four at a time: problem sizes for which the library picks
-    chunk lengths that leave one, two, three or no rows over, and one chunk for the whole graph.  The plan is read back
+    """The backward edge kernel walks the rows i of a chunk four at a time (eight in a packed ragged column tile): problem
+    sizes for which the library's chunks leave one, two, three or no rows over, and one chunk for the whole graph.  The plan is read back
     through gcn_layer_plan, so a change of the library's choice shows up here instead of silently dropping a case."""
     from hip_layer_check import check_layer_against_oracle
     from src.gcn.hip import lib as L
