@@ -972,7 +972,9 @@ int gcn_layer_plan(int B, int V, int C, int H, int out[8]) {
     const LayerFwdWs fw = carve_fwd_ws(d, f);
     const size_t units = (size_t)d.B * d.nit * d.njt * d.C;
     out[0] = d.IT; out[1] = d.nit; out[2] = d.njt; out[3] = fw.nblk; out[4] = range_blocks(units, d.grid_b);
-    out[5] = d.MT > 4 ? 1 : 0; out[6] = d.two_blocks ? 1 : 0; out[7] = 0;
+    out[5] = d.MT > 4 ? 1 : 0; out[6] = d.two_blocks ? 1 : 0;
+    out[7] = (d.MT > 4 && V - 16 * (d.njt - 1) <= 8) ? 1 : 0;       // the last column tile runs in k_edge_bwd_wp
+    if (out[7]) out[4] = d.njt > 1 ? range_blocks((size_t)d.B * d.nit * (d.njt - 1) * d.C, d.grid_b) : 0;
     return 0;
 }
 

@@ -178,11 +178,12 @@ def load():
 
 def layer_plan(B, V, C, H):
     """The library's launch plan for a problem size: dict with the row-chunk length of the edge backward pass
-    (``row_chunk``), chunks per graph, j tiles, edge-kernel grids and whether the wide kernels run."""
+    (``row_chunk``), chunks per graph, j tiles, edge-kernel grids, whether the wide kernels run and whether a ragged last
+    j tile gets the packed-tile launch of the wide backward pass."""
     out = (c_int * 8)()
     check(load().gcn_layer_plan(B, V, C, H, out), "gcn_layer_plan")
     return dict(row_chunk=out[0], n_chunks=out[1], j_tiles=out[2], grid_fwd=out[3], grid_bwd=out[4], wide=bool(out[5]),
-                two_blocks=bool(out[6]))
+                two_blocks=bool(out[6]), packed_last_tile=bool(out[7]))
 
 
 def check(rc, what):

@@ -63,7 +63,9 @@ int gcn_prof_end(double* total_ms, int* launches);
  * j tiles per (graph, row, commodity), out[3] / out[4] = workgroups of the forward / backward edge kernel,
  * out[5] = 1 if the weight-streaming kernels (hidden_dim > 64) run, out[6] = 1 if the edge kernels with two column
  * blocks per wavefront and the weight-gradient product fused into the backward kernel run (hidden_dim of 2 or 4
- * column blocks, about 300,000 edge rows or more), out[7] = 0. */
+ * column blocks, about 300,000 edge rows or more), out[7] = 1 if a ragged last j tile (at most 8 of its 16 columns in
+ * use, hidden_dim > 64) runs in a launch of its own with several rows packed into a tile; out[4] then counts the
+ * workgroups of the launch for the other j tiles (0 if there is none). */
 int gcn_layer_plan(int B, int V, int C, int H, int out[8]);
 size_t gcn_layer_saved_floats(int B, int V, int C, int H);
 size_t gcn_layer_ws_bytes(int B, int V, int C, int H);

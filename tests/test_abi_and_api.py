@@ -116,9 +116,12 @@ def test_launch_plan_is_sane_over_a_grid_of_shapes():
             it, n = plan["row_chunk"], plan["n_chunks"]
             assert 1 <= it <= V and n == -(-V // it), (B, V, C, H, plan)
             assert n * it - V < it                                  # the last chunk is not empty
-            assert -(-V // n) == it or H > 64                       # equal chunks (the wide path rounds to threes)
+            assert -(-V // n) == it or H > 64                       # equal chunks (the wide path rounds up to fours)
             assert plan["j_tiles"] == -(-V // 16)
-            assert 1 <= plan["grid_fwd"] <= 2048 and 1 <= plan["grid_bwd"] <= 2048
+            assert 1 <= plan["grid_fwd"] <= 2048 and (0 if plan["packed_last_tile"] else 1) <= plan["grid_bwd"] <= 2048
+            assert plan["packed_last_tile"] == (H > 64 and V - 16 * (plan["j_tiles"] - 1) <= 8)
+            if H > 64:
+                assert it % 4 == 0 or it == V                       # the wide kernels walk a chunk four rows at a time
             assert plan["wide"] == (H > 64)
             if H <= 64:
                 assert plan["grid_fwd"] % 8 == 0
@@ -153,3 +156,24 @@ def test_metrics_logger_books_what_the_trainer_reports(tmp_path):
     assert "final_train_loss" in open(tpath).read()
     line = metrics_to_str(3, 1.5, 1e-3, 0.25, 1.1, 1.0, 90.0, 0.0, comp_rate=99.0)
     assert line.startswith("epoch:03\texecution time:1.50000000s\tlr:1.00e-03\tloss:0.2500\t") and line.endswith("comp_rate:99.00%")
+
+
+def test_wide_launch_plan_row_chunks_and_ragged_tile():
+    """Host-side plan of the wide backward pass (no GPU needed): row chunks are multiples of four rows chosen for the
+    fewest steps on the busiest of 256 workgroups, and a last column tile with at most 8 of 16 columns in use gets the
+    packed-tile launch."""
+    from src.gcn.hip import lib as L
+    p = L.layer_plan(2, 100, 50, 300)          # 7 column tiles, the last with 4 columns
+    assert p["wide"] and p["packed_last_tile"] and (p["row_chunk"], p["n_chunks"], p["j_tiles"]) == (20, 5, 7)
+    assert p["grid_bwd"] == 250                # 3,000 units of the six full tiles: 12 per workgroup
+    p = L.layer_plan(2, 96, 50, 300)           # six full tiles
+    assert p["wide"] and not p["packed_last_tile"] and p["row_chunk"] % 4 == 0
+    p = L.layer_plan(1, 7, 256, 80)            # one tile of 7 columns: only the packed-tile launch runs
+    assert p["packed_last_tile"] and p["grid_bwd"] == 0 and (p["row_chunk"], p["n_chunks"]) == (7, 1)
+    p = L.layer_plan(1, 40, 40, 80)            # 16 + 16 + 8 columns
+    assert p["packed_last_tile"] and p["j_tiles"] == 3
+    p = L.layer_plan(1, 44, 40, 80)            # 16 + 16 + 12 columns: walked like a full tile
+    assert not p["packed_last_tile"]
+    p = L.layer_plan(20, 14, 10, 64)           # the strip path has no such launch
+    assert not p["wide"] and not p["packed_last_tile"]
+
