@@ -184,7 +184,8 @@ Dims make_dims(int B, int V, int C, int H) {
         // Row chunks of the wide backward kernel: a workgroup takes a contiguous range of (b, chunk, column tile, c) units of
         // ceil(IT / SNS) steps each, and the launch lasts as long as the workgroup with the most units: the chunk count n
         // (chunks of equal length, a multiple of SNS rows) with the fewest steps on that workgroup, a unit's fixed work
-        // (column sums written, node rows fetched) counted as 0.15 of a step.  100 nodes x 50 commodities, 2 graphs:
+        // (column sums written, node rows fetched) counted as 0.15 of a step, and the node backward kernel's reads of the
+        // 2 n column-sum tensors as 0.6 % of the launch each (measured: + 44 us at n = 5 against n = 2).  100 nodes x 50 commodities, 2 graphs:
         // 5 chunks of 20 rows (3,000 units, 12 x 5 steps) instead of 2 of 52 / 48 (1,200 units, 5 x 13 steps): 2.61 ->
         // 2.48 ms per layer, 190.7 -> 184.0 ms per step.
         const int njt_main = (d.njt > 1 && V - 16 * (d.njt - 1) <= 8) ? d.njt - 1 : d.njt;   // a ragged last tile has its own launch
@@ -192,7 +193,7 @@ Dims make_dims(int B, int V, int C, int H) {
         for (int n = 1; n <= (V + SNS - 1) / SNS; ++n) {
             const int it = std::min(V, ((V + n - 1) / n + SNS - 1) / SNS * SNS), nn = (V + it - 1) / it;
             const long long units = (long long)B * nn * njt_main * C, per = (units + d.grid_b - 1) / d.grid_b;
-            const double c = (double)per * ((it + SNS - 1) / SNS + 0.15);
+            const double c = (double)per * ((it + SNS - 1) / SNS + 0.15) * (1.0 + 0.6 * nn / V);   // + the node kernel's 2 n column-sum slots
             if (bestc < 0 || c < bestc) { bestc = c; d.IT = it; }
         }
     }

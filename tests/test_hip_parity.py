@@ -275,7 +275,7 @@ def test_wide_layer_forward_backward_matches_oracle(B, V, C, H, agg):
     (1, 18, 44, 128, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 2 rows: whole steps and a last chunk of half a step
     (1, 18, 72, 128, "sum", 8, 3),       # 8 + 8 + 2 rows
     (1, 19, 110, 80, "mean", 12, 2),     # 12 + 7 rows: the last chunk is 4 + 3, a step with one row missing
-    (1, 17, 200, 80, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 1 rows: a last chunk of a single row
+    (1, 17, 100, 80, "mean", 4, 5),      # 4 + 4 + 4 + 4 + 1 rows: a last chunk of a single row
     (1, 40, 40, 80, "sum", 16, 3),       # 16 + 16 + 8 rows: whole steps, three j tiles (the last one half full: packed tiles)
     (4, 7, 256, 80, "mean", 7, 1),       # one chunk for the whole graph: 4 + 3 (a single, packed column tile)
     (1, 22, 300, 80, "mean", 8, 3),      # 8 + 8 + 6 rows, a ragged second j tile of 6 columns (two rows i per tile)
