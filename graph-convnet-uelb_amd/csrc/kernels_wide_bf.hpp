@@ -675,12 +675,12 @@ __global__ __launch_bounds__(STH) void k_edge_bwd_ws(EdgeBwdArgs a) {
 // Edge backward of the ragged last column tile (EdgeBwdArgs with jt_lo = that tile, jt_n = 1; same math and outputs as
 // k_edge_bwd_ws for its units (b, it, jt_lo, c)).  When the node count is no multiple of 16 and the last tile has at
 // most 8 of its 16 columns j in use, a 16-row tile in LDS holds P rows i of 16 / P columns each (P = 2, or 4 with at
-// most 4 columns) and a step takes BQR rows i: at 100 nodes the seventh column tile has 4 columns, and walked like the
+// most 4 columns) and a step takes 8 rows i (P = 2) or 10 (P = 4): at 100 nodes the seventh column tile has 4 columns, and walked like the
 // others it costs a seventh of the kernel's time for 4 % of its rows (2.85 ms per launch against 2.48 at 96 nodes per
 // million rows).  A kernel of its own so that the layout arithmetic does not cost the main kernel registers.
 // Dynamic LDS: 3 SPB bytes.
 // ------------------------------------------------------------------------------------------------
-constexpr int BQR = 8;          // rows i per step of a packed (P > 1) unit = rows of node-side terms kept in LDS
+constexpr int BQR = 10;         // most rows i per step of a packed unit = rows of node-side terms kept in LDS (what fits beside the planes)
 // sum over the 16 / P lanes of a tile that belong to the same row i (every lane receives its group's sum); P = 2, 4.
 // Cross-lane moves through the LDS crossbar: packed tiles are the exception, and the order of the additions is fixed.
 __device__ __forceinline__ f32x4 red_group4(f32x4 v, int P) {
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(STH) void k_edge_bwd_wp(EdgeBwdArgs a) {
     const int jt = a.jt_lo;
     const int vj = min(16, V - 16 * jt);
     const int lg = vj <= 4 ? 2 : 3, JW = 1 << lg, P = 16 >> lg;                          // columns j per tile row group, rows i per tile
-    const int srows = BQR;                                                                  // rows i per step
+    const int srows = P == 4 ? BQR : 8;                                                     // rows i per step: at most SNS tiles of P rows
     for (int u = u0; u < u1; ++u) {
         int tt = u;
         const int c = tt % C; tt /= C;
