@@ -202,7 +202,13 @@ __device__ __forceinline__ void split_gemm_n(const unsigned char* planes, int ns
 // the matrix pipe idle and a product phase with HBM idle: 39 % + 42 % of the kernel).
 // partial layout [gridDim.x][4][H].  Dynamic LDS: 3 SPB bytes.
 // ------------------------------------------------------------------------------------------------
-constexpr int SFT = 768;        // threads of the forward kernel: 512 multiplying + 256 staging
+#ifndef GCN_FMW
+#define GCN_FMW 8      // measurement builds may set 4 (one multiplying wavefront per SIMD, 256 registers, no scratch: 201 ms per step against 184-187 at H = 300)
+#endif
+constexpr int FMW = GCN_FMW;                 // multiplying wavefronts of the forward kernel
+constexpr int FMT = 64 * FMW;                // their threads
+constexpr int FKB = (WNB + FMW - 1) / FMW;   // column blocks per multiplying wavefront
+constexpr int SFT = FMT + 256;               // threads of the forward kernel: multiplying + 256 staging
 // A step of the row sequence: it starts at row j0 of unit u and holds n rows (rows past the end of unit u belong to
 // unit u + 1: at most one boundary per step).
 struct FwdStep {
@@ -238,9 +244,9 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
     const int u0 = (int)blockIdx.x * per, u1 = min(units, u0 + per);
     const bool span = V >= 16 * SNS;
     __syncthreads();
-    if (threadIdx.x >= STH) {
+    if (threadIdx.x >= FMT) {
         // ---------------------------------------------------------------- staging wavefronts
-        const int pt = threadIdx.x - STH, arow = pt >> 4, g0 = pt & 15;
+        const int pt = threadIdx.x - FMT, arow = pt >> 4, g0 = pt & 15;
         const DropCfg dc = drop_cfg(a.rng, S.drop_sid, S.drop_p, S.drop_on && S.mode == 1);
         f32x4 val[SNS][WKA];
         // rows 16 s + arow of a step: layer input -> val (zeros outside the step), written to e_out
@@ -346,8 +352,8 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
         __syncthreads();
         ACCF(1);
 #pragma unroll 1
-        for (int kk = 0; kk < SKB8; ++kk) {
-            const int nb = ix.w + 8 * kk;
+        for (int kk = 0; kk < FKB; ++kk) {
+            const int nb = ix.w + FMW * kk;
             if (nb < NB) {
                 const int bcol = 16 * nb + 4 * ix.q;
                 // epilogue operands are requested before the product so that their latency hides under it
@@ -397,8 +403,8 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
         // ---- unit u ends with this step: the lane that accumulated these columns finishes it
         if (st.j0 + st.n >= V) {
 #pragma unroll
-            for (int k = 0; k < SKB8; ++k) {
-                const int nb = ix.w + 8 * k;
+            for (int k = 0; k < FKB; ++k) {
+                const int nb = ix.w + FMW * k;
                 if (nb < NB) {
                     const int bcol = 16 * nb + 4 * ix.q;
                     if (ix.rs == 0 && bcol < H) {
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(SFT) void k_edge_fwd_ws(EdgeFwdArgs a) {
         fwd_step_next(u, j0, st.n, V);
     }
 #pragma unroll
-    for (int k = 0; k < SKB8; ++k) {
-        const int nb = ix.w + 8 * k;
+    for (int k = 0; k < FKB; ++k) {
+        const int nb = ix.w + FMW * k;
         if (nb < NB) {
             const int bcol = 16 * nb + 4 * ix.q;
             if (ix.rs == 0 && bcol < H) {       // the lane that accumulated these columns
