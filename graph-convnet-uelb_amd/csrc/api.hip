@@ -230,6 +230,16 @@ inline int head_blocks(size_t tiles, bool forward, int H, bool two_blocks = fals
 }
 // grid of the one-workgroup-per-unit kernels (grid-stride beyond the cap)
 inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<size_t>(1, std::min<size_t>(units, (size_t)cap)); }
+// Grid of the strip node kernels (one 16-row tile per workgroup and trip, grid-stride beyond the cap).  A workgroup's
+// prologue (three weight matrices as MFMA fragments, BatchNorm constants) costs as much as a few tiles, and every workgroup
+// of the backward kernel adds a row of partial sums to reduce: one workgroup per CU up to 2048 tiles, two from there on
+// (nsfnet_10 at 80 graphs, 700 tiles: 1.870 ms per step on 700 workgroups, 1.841 on 512, 1.808 on 384, 1.786 on 256, 1.833 on
+// 128; at 320 graphs, 2800 tiles: 5.79 on 2048, 5.68 on 1024, 5.62 on 768, 5.59 on 512, 5.63 on 384, 5.68 on 256).
+inline int node_blocks(size_t tiles, int cap = 2048) {
+    cap = std::min(cap, tiles >= 2048 ? 512 : 256);
+    if (const char* e = tune_env("GCN_TUNE_GRID_N")) cap = std::max(1, std::min(atoi(e), 2048));
+    return strip_blocks(tiles, cap);
+}
 // grid of a kernel whose workgroups each take a contiguous range of units: no workgroup is left without work
 inline int range_blocks(size_t units, int cap) {
     const size_t per = (units + cap - 1) / cap;
@@ -413,7 +423,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
         a.rng = rng;
         if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_fwd_w", k_node_fwd_w, strip_blocks((d.Rn + 15) / 16), 256, a);
-        else GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), strip_blocks((d.Rn + 15) / 16), 64 * MT, a);
+        else GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), node_blocks((d.Rn + 15) / 16), 64 * MT, a);
     }
     {
         EdgeFwdArgs a = {};
@@ -1438,7 +1448,7 @@ int gcn_model_bwd_ev(const gcn_model_desc* m, const float* cap, const float* dem
             if (head_tn_pending) { jobs.job[nj++] = head_tn_job; head_tn_pending = false; }    // top layer only: nj <= 2 there
             jobs.n = nj;
             MidMap map = {};
-            int nb = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+            int nb = node_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
             if (const char* e = tune_env("GCN_TUNE_MIDPROBE")) {     // timing probe: segments of the launch dropped (results are then wrong)
                 const int mk = atoi(e);
                 if (mk & 1) nb = 0;
