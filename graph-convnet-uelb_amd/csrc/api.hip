@@ -235,6 +235,11 @@ inline int strip_blocks(size_t units, int cap = 2048) { return (int)std::max<siz
 // of the backward kernel adds a row of partial sums to reduce: one workgroup per CU up to 2048 tiles, two from there on
 // (nsfnet_10 at 80 graphs, 700 tiles: 1.870 ms per step on 700 workgroups, 1.841 on 512, 1.808 on 384, 1.786 on 256, 1.833 on
 // 128; at 320 graphs, 2800 tiles: 5.79 on 2048, 5.68 on 1024, 5.62 on 768, 5.59 on 512, 5.63 on 384, 5.68 on 256).
+// the same for the node kernels of the wide path (64 < H <= 320)
+inline int wide_node_blocks(size_t tiles, int cap = 2048) {
+    if (const char* e = tune_env("GCN_TUNE_GRID_NW")) cap = std::max(1, std::min(atoi(e), 2048));
+    return strip_blocks(tiles, cap);
+}
 inline int node_blocks(size_t tiles, int cap = 2048) {
     cap = std::min(cap, tiles >= 2048 ? 512 : 256);
     if (const char* e = tune_env("GCN_TUNE_GRID_N")) cap = std::max(1, std::min(atoi(e), 2048));
@@ -422,7 +427,7 @@ int layer_fwd_core(const Dims& d, int agg, float p, int training, const unsigned
         a.W[1] = P[2]; a.bias[1] = P[3]; a.y[1] = S.Vn;
         a.W[2] = P[6]; a.bias[2] = P[7]; a.y[2] = W.Ve;
         a.rng = rng;
-        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_fwd_w", k_node_fwd_w, strip_blocks((d.Rn + 15) / 16), 256, a);
+        if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_fwd_w", k_node_fwd_w, wide_node_blocks((d.Rn + 15) / 16), 256, a);
         else GCN_LAUNCH_TIMED("k_node_fwd3", (k_node_fwd3<MT>), node_blocks((d.Rn + 15) / 16), 64 * MT, a);
     }
     {
@@ -607,7 +612,7 @@ int layer_bwd_data(const Dims& d, int agg, float p, int training, const unsigned
     }
     if (int rc = launch_edge_bwd<MT>(d, agg, p, training, rng, sid, P, wT, S, dx, de, e_in, tn_e, W, npart_e, nx, st)) return rc;
     {
-        const int blocks = strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
+        const int blocks = MT == 0 ? wide_node_blocks((d.Rn + 15) / 16, kMaxPartBlocks) : strip_blocks((d.Rn + 15) / 16, kMaxPartBlocks);
         const NodeBwdArgs a = node_bwd_args(d, p, training, rng, sid, P, wT, S, dx, W, W.dxtmp, W.dVn, W.dVe, nx);
         if constexpr (MT == 0) GCN_LAUNCH_TIMED("k_node_bwd_w", k_node_bwd_w, blocks, 256, a);
         else GCN_LAUNCH_TIMED("k_node_bwd3", (k_node_bwd3<MT>), blocks, 64 * MT, a);
