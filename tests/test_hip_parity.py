@@ -197,7 +197,9 @@ def test_model_matches_reference_golden(path):
     assert_grads_close(((k, p.grad) for k, p in model.named_parameters()), ref64, {k: g["grad." + k] for k in ref64})
 
 
-@pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (2, 2, 384, 96, 2), (2, 2, 384, 304, 2)])
+@pytest.mark.parametrize("B,V,C,H,chunk", [(3, 14, 4, 64, 0), (2, 2, 384, 96, 2), (2, 2, 384, 304, 2),
+                                           (1, 20, 24, 96, 0),     # 16 + 4 columns: the full-tile launch and the packed one (4 rows per tile)
+                                           (1, 24, 12, 96, 0)])    # 16 + 8 columns: two rows per tile in the packed launch
 def test_layer_train_mode_dropout_semantics(B, V, C, H, chunk):
     """Train-mode outputs cannot match the reference bit for bit (different RNG).  Check instead that
     (1) ~(1-p) of the elements survive, (2) the output equals the oracle's pre-dropout output times
